@@ -1,0 +1,639 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING the reference.
+
+This script is the only place where the reference (pyVBMP @ /root/reference) is
+imported.  It runs only in the build container (the reference never travels to
+the GPU box) and writes nothing but DATA: the inputs that were fed to a
+reference method and the tensors that the reference returned / left in its
+attributes.  No reference source text is stored.
+
+    python tools/gen_golden.py            # all groups
+    python tools/gen_golden.py niw mnw    # selected groups
+
+Each group becomes tests/golden/<group>.npz with keys "<case>/<field>".
+fp64 everywhere (torch.set_default_dtype BEFORE importing the reference, because
+the reference builds its default prior tensors at import time).
+"""
+import os
+import sys
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+
+torch.set_default_dtype(torch.float64)
+REF = os.environ.get("VBMP_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+
+import dists  # noqa: E402  (reference)
+import transforms  # noqa: E402
+import utils  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+class Book:
+    """Collects tensors under "<case>/<field>" keys."""
+
+    def __init__(self):
+        self.d = {}
+        self.case = None
+
+    def begin(self, case):
+        self.case = case
+
+    def put(self, name, value):
+        if value is None:
+            return
+        if isinstance(value, torch.Tensor):
+            value = value.detach().clone().cpu().numpy()
+        self.d[f"{self.case}/{name}"] = np.asarray(value)
+
+    def save(self, group):
+        os.makedirs(OUT, exist_ok=True)
+        path = os.path.join(OUT, group + ".npz")
+        np.savez_compressed(path, **self.d)
+        print(f"{group}: {len(self.d)} arrays, {os.path.getsize(path)/1024:.1f} KiB")
+
+
+def spd_stats(batch, D, n, gen):
+    """Sufficient statistics of n pseudo-samples per batch element."""
+    A = torch.randn(batch + (D, n), generator=gen)
+    SExx = A @ A.transpose(-2, -1)
+    SEx = A.sum(-1)
+    return SExx, SEx
+
+
+def rand_spd(shape, D, gen, jitter=0.5):
+    A = torch.randn(shape + (D, D + 2), generator=gen)
+    return A @ A.transpose(-2, -1) / (D + 2) + jitter * torch.eye(D)
+
+
+# ------------------------------------------------------------------ Wishart
+def snap_wishart(b, w, prefix=""):
+    for f in ("invU", "U", "nu", "logdet_invU"):
+        b.put(prefix + f, getattr(w, f))
+
+
+def snap_wishart_expect(b, w, prefix=""):
+    for f in ("mean", "meaninv", "ESigma", "EinvSigma", "invEinvSigma", "ElogdetinvSigma",
+              "logdetEinvSigma", "KLqprior", "logZ"):
+        b.put(prefix + f, getattr(w, f)())
+
+
+def gen_wishart():
+    b = Book()
+    gen = torch.Generator().manual_seed(101)
+    for D in (2, 6, 16):
+        for lr in (1.0, 0.5):
+            for beta in (None, 0.9):
+                b.begin(f"w_d{D}_lr{lr}_beta{beta}")
+                scale = 0.7
+                w = dists.Wishart(event_shape=(D, D), batch_shape=(6,), scale=torch.tensor(scale))
+                b.put("scale", scale)
+                b.put("lr", lr)
+                b.put("beta", -1.0 if beta is None else beta)
+                snap_wishart(b, w, "init_")
+                b.put("invU_0", w.invU_0)
+                b.put("nu_0", w.nu_0)
+                b.put("logdet_invU_0", w.logdet_invU_0)
+                for step in (1, 2):
+                    SExx, _ = spd_stats((6,), D, 2 * D + step, gen)
+                    N = torch.full((6,), 2.0 * D + step) + torch.rand(6, generator=gen)
+                    b.put(f"SExx{step}", SExx)
+                    b.put(f"N{step}", N)
+                    w.ss_update(SExx, N, lr=lr, beta=beta)
+                    snap_wishart(b, w, f"s{step}_")
+                snap_wishart_expect(b, w)
+    # extra event dims + to_event
+    b.begin("w_event322")
+    w = dists.Wishart(event_shape=(3, 2, 2), batch_shape=(5, 6), scale=torch.tensor(1.3))
+    SExx, _ = spd_stats((5, 6, 3), 2, 7, gen)
+    N = 7.0 + torch.rand(5, 6, 3, generator=gen)
+    b.put("SExx1", SExx)
+    b.put("N1", N)
+    w.ss_update(SExx, N, lr=0.8)
+    snap_wishart(b, w, "s1_")
+    snap_wishart_expect(b, w)
+    w.to_event(1)
+    b.put("KLqprior_to_event1", w.KLqprior())
+    b.save("wishart")
+
+
+# ---------------------------------------------------------------------- NIW
+def snap_niw(b, q, prefix=""):
+    b.put(prefix + "lambda_mu", q.lambda_mu)
+    b.put(prefix + "mu", q.mu)
+    snap_wishart(b, q.invU, prefix)
+
+
+def snap_niw_expect(b, q, prefix=""):
+    for f in ("mean", "EX", "EXXT", "ESigma", "ElogdetinvSigma", "EinvSigmamu", "EinvSigma", "EinvUX",
+              "EXTinvUX", "KLqprior"):
+        b.put(prefix + f, getattr(q, f)())
+
+
+def gen_niw():
+    b = Book()
+    gen = torch.Generator().manual_seed(202)
+
+    # --- D=16 flat batch: the headline layout (config 2, small)
+    for lr in (1.0, 0.5):
+        b.begin(f"niw_d16_lr{lr}")
+        q = dists.NormalInverseWishart(event_shape=(16,), batch_shape=(8,))
+        b.put("lr", lr)
+        snap_niw(b, q, "init_")
+        for step in (1, 2):
+            SExx, SEx = spd_stats((8,), 16, 32, gen)
+            N = torch.full((8,), 32.0)
+            b.put(f"SExx{step}", SExx)
+            b.put(f"SEx{step}", SEx)
+            b.put(f"N{step}", N)
+            q.ss_update(SExx, SEx, N, lr=lr)  # beta defaults to 0.0
+            snap_niw(b, q, f"s{step}_")
+        snap_niw_expect(b, q)
+        X1 = torch.randn(7, 1, 16, generator=gen)
+        X2 = torch.randn(7, 8, 16, generator=gen)
+        b.put("X_bcast", X1)
+        b.put("X_full", X2)
+        b.put("Elog_like_bcast", q.Elog_like(X1))
+        b.put("Elog_like_full", q.Elog_like(X2))
+
+    # --- forgetting factor
+    b.begin("niw_beta0.9")
+    q = dists.NormalInverseWishart(event_shape=(6,), batch_shape=(8,), scale=torch.tensor(0.5))
+    snap_niw(b, q, "init_")
+    for step in (1, 2, 3):
+        SExx, SEx = spd_stats((8,), 6, 10, gen)
+        N = 10.0 + torch.rand(8, generator=gen)
+        b.put(f"SExx{step}", SExx)
+        b.put(f"SEx{step}", SEx)
+        b.put(f"N{step}", N)
+        q.ss_update(SExx, SEx, N, lr=0.7, beta=0.9)
+        snap_niw(b, q, f"s{step}_")
+    snap_niw_expect(b, q)
+
+    # --- raw_update, with and without responsibilities
+    b.begin("niw_raw")
+    q = dists.NormalInverseWishart(event_shape=(5,), batch_shape=(4,))
+    snap_niw(b, q, "init_")
+    X = torch.randn(50, 1, 5, generator=gen) * 2.0 + 1.0
+    p = torch.softmax(torch.randn(50, 4, generator=gen), -1)
+    b.put("X", X)
+    b.put("p", p)
+    q.raw_update(X, p, lr=1.0)
+    snap_niw(b, q, "p_")
+    q.raw_update(X, p, lr=0.3)
+    snap_niw(b, q, "p2_")
+    Xf = torch.randn(50, 4, 5, generator=gen)
+    b.put("X_full", Xf)
+    q.raw_update(Xf, None, lr=1.0)
+    snap_niw(b, q, "nop_")
+    snap_niw_expect(b, q)
+
+    # --- extra event dims (3,2) and batch (5,6)
+    b.begin("niw_e32_b56")
+    q = dists.NormalInverseWishart(event_shape=(3, 2), batch_shape=(5, 6), scale=torch.tensor(0.8))
+    snap_niw(b, q, "init_")
+    SExx, SEx = spd_stats((5, 6, 3), 2, 9, gen)
+    N = 9.0 + torch.rand(5, 6, 1, generator=gen)
+    b.put("SExx1", SExx)
+    b.put("SEx1", SEx)
+    b.put("N1", N)
+    q.ss_update(SExx, SEx, N, lr=1.0)
+    snap_niw(b, q, "s1_")
+    X = torch.randn(9, 1, 1, 3, 2, generator=gen)
+    p = torch.softmax(torch.randn(9, 5 * 6, generator=gen), -1).view(9, 5, 6)
+    b.put("X", X)
+    b.put("p", p)
+    b.put("Elog_like", q.Elog_like(X))
+    q.raw_update(X, p, lr=0.6)
+    snap_niw(b, q, "raw_")
+    snap_niw_expect(b, q)
+
+    # --- to_event(1): event (6,2), batch (5,)
+    b.begin("niw_toevent")
+    q = dists.NormalInverseWishart(event_shape=(2,), batch_shape=(5, 6))
+    snap_niw(b, q, "init_")
+    SExx, SEx = spd_stats((5, 6), 2, 6, gen)
+    N = 6.0 + torch.rand(5, 6, generator=gen)
+    b.put("SExx1", SExx)
+    b.put("SEx1", SEx)
+    b.put("N1", N)
+    q.ss_update(SExx, SEx, N)
+    q.to_event(1)
+    X = torch.randn(7, 1, 6, 2, generator=gen)
+    b.put("X", X)
+    b.put("Elog_like", q.Elog_like(X))
+    b.put("KLqprior", q.KLqprior())
+
+    # --- fixed precision
+    b.begin("niw_fixed_precision")
+    q = dists.NormalInverseWishart(event_shape=(4,), batch_shape=(3,), fixed_precision=True)
+    snap_niw(b, q, "init_")
+    SExx, SEx = spd_stats((3,), 4, 8, gen)
+    N = torch.full((3,), 8.0)
+    b.put("SExx1", SExx)
+    b.put("SEx1", SEx)
+    b.put("N1", N)
+    q.ss_update(SExx, SEx, N, lr=0.9)
+    snap_niw(b, q, "s1_")
+
+    # --- user prior
+    b.begin("niw_prior")
+    prior = {"lambda_mu": torch.tensor(2.0), "mu": torch.tensor(0.5),
+             "nu": torch.full((3,), 9.0), "invU": rand_spd((3,), 4, gen)}
+    for k, v in prior.items():
+        b.put("prior_" + k, v)
+    q = dists.NormalInverseWishart(event_shape=(4,), batch_shape=(3,), prior_parms=prior)
+    snap_niw(b, q, "init_")
+    SExx, SEx = spd_stats((3,), 4, 8, gen)
+    N = torch.full((3,), 8.0)
+    b.put("SExx1", SExx)
+    b.put("SEx1", SEx)
+    b.put("N1", N)
+    q.ss_update(SExx, SEx, N)
+    snap_niw(b, q, "s1_")
+    snap_niw_expect(b, q)
+    b.save("niw")
+
+
+# ---------------------------------------------------------------------- MVN
+def gen_mvn():
+    b = Book()
+    gen = torch.Generator().manual_seed(303)
+    D = 5
+    # plain format
+    b.begin("mvn_from_moments")
+    mu = torch.randn(4, 3, D, generator=gen)
+    Sigma = rand_spd((4, 3), D, gen)
+    b.put("mu", mu)
+    b.put("Sigma", Sigma)
+    q = dists.MultivariateNormal(mu=mu, Sigma=Sigma)
+    for f in ("EinvSigma", "EinvSigmamu", "ElogdetinvSigma", "EXXT", "EXTX", "EX", "mean", "ESigma"):
+        b.put(f, getattr(q, f)())
+    X = torch.randn(6, 4, 3, D, generator=gen)
+    b.put("X", X)
+    b.put("Elog_like", q.Elog_like(X))
+
+    b.begin("mvn_from_natural")
+    invSigma = rand_spd((4, 3), D, gen)
+    invSigmamu = torch.randn(4, 3, D, generator=gen)
+    b.put("invSigma", invSigma)
+    b.put("invSigmamu", invSigmamu)
+    q = dists.MultivariateNormal(invSigma=invSigma, invSigmamu=invSigmamu)
+    for f in ("mean", "ESigma", "ElogdetinvSigma", "EXXT", "EXTX"):
+        b.put(f, getattr(q, f)())
+
+    b.begin("mvn_updates")
+    q = dists.MultivariateNormal(mu=torch.zeros(3, D), Sigma=torch.eye(D).expand(3, D, D))
+    X = torch.randn(40, 1, D, generator=gen)
+    p = torch.softmax(torch.randn(40, 3, generator=gen), -1)
+    b.put("X", X)
+    b.put("p", p)
+    q.raw_update(X, p)
+    b.put("p_mu", q.mu)
+    b.put("p_Sigma", q.Sigma)
+    Xf = torch.randn(40, 3, D, generator=gen)
+    b.put("X_full", Xf)
+    q.raw_update(Xf)
+    b.put("nop_mu", q.mu)
+    b.put("nop_Sigma", q.Sigma)
+    b.put("nop_EinvSigma", q.EinvSigma())
+    b.put("nop_EinvSigmamu", q.EinvSigmamu())
+
+    # vector format
+    b.begin("vf_from_moments")
+    mu = torch.randn(4, 3, D, 1, generator=gen)
+    Sigma = rand_spd((4, 3), D, gen)
+    b.put("mu", mu)
+    b.put("Sigma", Sigma)
+    q = dists.MultivariateNormal_vector_format(mu=mu, Sigma=Sigma)
+    for f in ("EinvSigma", "EinvSigmamu", "ElogdetinvSigma", "EXXT", "EXTX", "Res", "mean", "ESigma"):
+        b.put(f, getattr(q, f)())
+    X = torch.randn(6, 4, 3, D, 1, generator=gen)
+    b.put("X", X)
+    b.put("Elog_like", q.Elog_like(X))
+
+    b.begin("vf_from_natural")
+    invSigma = rand_spd((4, 3), D, gen)
+    invSigmamu = torch.randn(4, 3, D, 1, generator=gen)
+    b.put("invSigma", invSigma)
+    b.put("invSigmamu", invSigmamu)
+    q = dists.MultivariateNormal_vector_format(invSigma=invSigma, invSigmamu=invSigmamu)
+    for f in ("mean", "ESigma", "ElogdetinvSigma", "EXXT", "EXTX", "Res"):
+        b.put(f, getattr(q, f)())
+    other_P = rand_spd((4, 3), D, gen)
+    other_eta = torch.randn(4, 3, D, 1, generator=gen)
+    b.put("other_invSigma", other_P)
+    b.put("other_invSigmamu", other_eta)
+    q.nat_combiner(other_P, other_eta)
+    b.put("nat_invSigma", q.invSigma)
+    b.put("nat_invSigmamu", q.invSigmamu)
+    b.put("nat_mean", q.mean())
+    b.put("nat_Res", q.Res())
+    o = dists.MultivariateNormal_vector_format(invSigma=other_P, invSigmamu=other_eta)
+    q.combiner(o)
+    b.put("comb_invSigma", q.invSigma)
+    b.put("comb_invSigmamu", q.invSigmamu)
+    b.put("comb_ESigma", q.ESigma())
+    u = q.unsqueeze(-3)
+    b.put("unsq_invSigma_shape", np.array(u.invSigma.shape))
+    b.put("unsq_batch_shape", np.array(u.batch_shape))
+
+    b.begin("vf_updates")
+    q = dists.MultivariateNormal_vector_format(mu=torch.zeros(3, D, 1), Sigma=torch.eye(D).expand(3, D, D))
+    X = torch.randn(40, 1, D, 1, generator=gen)
+    p = torch.softmax(torch.randn(40, 3, generator=gen), -1)
+    b.put("X", X)
+    b.put("p", p)
+    q.raw_update(X, p)
+    b.put("p_mu", q.mu)
+    b.put("p_Sigma", q.Sigma)
+    Xf = torch.randn(40, 3, D, 1, generator=gen)
+    b.put("X_full", Xf)
+    q.raw_update(Xf)
+    b.put("nop_mu", q.mu)
+    b.put("nop_Sigma", q.Sigma)
+    b.save("mvn")
+
+
+# ------------------------------------------------------------- matrix_utils
+def gen_matrix_utils():
+    b = Book()
+    gen = torch.Generator().manual_seed(404)
+    mu_ = utils.matrix_utils
+    for name, (na, nd, batch) in {"mu_4_3": (4, 3, (7,)), "mu_6_6": (6, 6, (2, 5)), "mu_16_8": (16, 8, (3,))}.items():
+        b.begin(name)
+        J = rand_spd(batch, na + nd, gen, jitter=1.0)
+        A, B = J[..., :na, :na], J[..., :na, na:]
+        C, D = J[..., na:, :na], J[..., na:, na:]
+        for k, v in (("A", A), ("B", B), ("C", C), ("D", D)):
+            b.put(k, v)
+        b.put("block_diag", mu_.block_diag_matrix_builder(A, D))
+        b.put("block_build", mu_.block_matrix_builder(A, B, C, D))
+        for form in ("left", "right", "True"):
+            out = mu_.block_matrix_inverse(A, B, C, D, block_form=form)
+            for i, o in enumerate(out):
+                b.put(f"inv_{form}_{i}", o)
+        b.put("inv_full", mu_.block_matrix_inverse(A, B, C, D, block_form=False))
+        b.put("inv_default", mu_.block_matrix_inverse(A, B, C, D))
+        out = mu_.block_precision_marginalizer(A, B, C, D)
+        for i, o in enumerate(out):
+            b.put(f"marg_{i}", o)
+        b.put("logdet", mu_.block_matrix_logdet(A, B, C, D))
+        b.put("logdet_A", mu_.block_matrix_logdet(A, B, C, D, singular="A"))
+        b.put("logdet_D", mu_.block_matrix_logdet(A, B, C, D, singular="D"))
+    b.save("matrix_utils")
+
+
+# ---------------------------------------------------------------------- MNW
+def snap_mnw(b, m, prefix=""):
+    for f in ("mu", "invV", "V", "logdetinvV"):
+        b.put(prefix + f, getattr(m, f))
+    snap_wishart(b, m.invU, prefix + "invU_")
+
+
+def snap_mnw_expect(b, m, prefix=""):
+    for f in ("EinvUX", "EXTinvU", "EXTinvUX", "EXinvVXT", "EXmMUTinvUXmMU", "EXmMUinvVXmMUT", "ElogdetinvU",
+              "logdetEinvSigma", "ElogdetinvSigma", "EinvSigma", "invEinvSigma", "ESigma", "KLqprior", "mean",
+              "weights", "var"):
+        b.put(prefix + f, getattr(m, f)())
+    if m.batch_dim == 0 and m.event_dim == 2:
+        b.put(prefix + "EXTX", m.EXTX())
+        b.put(prefix + "EXXT", m.EXXT())
+        A = torch.eye(m.p) * 0.5 + 0.1
+        An = torch.eye(m.n) * 0.5 + 0.1
+        b.put(prefix + "EXTAX", m.EXTAX(An))
+        b.put(prefix + "EXAXT", m.EXAXT(A))
+
+
+def mnw_case(b, name, n, p, batch, pad_X, gen, mask=None, X_mask=None, N=24, lr2=0.5):
+    b.begin(name)
+    m = transforms.MatrixNormalWishart(event_shape=(n, p), batch_shape=batch, pad_X=pad_X, mask=mask, X_mask=X_mask)
+    b.put("n", n)
+    b.put("p", p)
+    b.put("pad_X", int(pad_X))
+    b.put("batch_shape", np.array(batch, dtype=np.int64))
+    if mask is not None:
+        b.put("mask", mask)
+    if X_mask is not None:
+        b.put("X_mask", X_mask)
+    snap_mnw(b, m, "init_")
+    nb = len(batch)
+    W = torch.randn(batch + (n, p), generator=gen)
+    X = torch.randn((N,) + (1,) * nb + (p, 1), generator=gen)
+    Y = W @ X + 0.3 * torch.randn((N,) + batch + (n, 1), generator=gen)
+    if nb:
+        pr = torch.softmax(torch.randn((N,) + batch, generator=gen), -1)
+    else:
+        pr = None
+    b.put("X", X)
+    b.put("Y", Y)
+    b.put("p_resp", pr)
+    # raw_update (data), lr=1 then lr2
+    Xe = X.expand((N,) + batch + (p, 1))
+    m.raw_update(Xe, Y, p=pr, lr=1.0)
+    snap_mnw(b, m, "raw1_")
+    m.raw_update(Xe, Y, p=pr, lr=lr2)
+    snap_mnw(b, m, "raw2_")
+    snap_mnw_expect(b, m, "raw2_")
+    # likelihoods
+    b.put("Elog_like", m.Elog_like(X, Y))
+    iSx, iSmx, R = m.Elog_like_X(Y)
+    b.put("ELX_invSigma", iSx)
+    b.put("ELX_invSigmamu", iSmx)
+    b.put("ELX_Res", R)
+    pY, R = m.predict(X)
+    b.put("predict_invSigma", pY.invSigma)
+    b.put("predict_invSigmamu", pY.invSigmamu)
+    b.put("predict_Res", R)
+    pX, R = m.postdict(Y)
+    b.put("postdict_invSigma", pX.invSigma)
+    b.put("postdict_invSigmamu", pX.invSigmamu)
+    b.put("postdict_Res", R)
+
+    # messages: per-sample precision (config-3 shape) and shared precision
+    px_P = rand_spd((N,) + (1,) * nb, p, gen)
+    px_eta = torch.randn((N,) + (1,) * nb + (p, 1), generator=gen)
+    b.put("fw_in_invSigma", px_P)
+    b.put("fw_in_invSigmamu", px_eta)
+    pXm = dists.MultivariateNormal_vector_format(invSigma=px_P.clone(), invSigmamu=px_eta.clone())
+    pYm, Res = m.forward(pXm)
+    b.put("fw_mu", pYm.mu)
+    b.put("fw_Sigma", pYm.Sigma)
+    b.put("fw_Res", Res)
+    shared_P = rand_spd((), p, gen)
+    b.put("fws_in_invSigma", shared_P)
+    pXs = dists.MultivariateNormal_vector_format(invSigma=shared_P.clone(), invSigmamu=px_eta.clone())
+    pYs, Res = m.forward(pXs)
+    b.put("fws_mu", pYs.mu)
+    b.put("fws_Sigma", pYs.Sigma)
+    b.put("fws_Res", Res)
+
+    py_P = rand_spd((N,) + (1,) * nb, n, gen)
+    py_eta = torch.randn((N,) + (1,) * nb + (n, 1), generator=gen)
+    b.put("bw_in_invSigma", py_P)
+    b.put("bw_in_invSigmamu", py_eta)
+    pYb = dists.MultivariateNormal_vector_format(invSigma=py_P.clone(), invSigmamu=py_eta.clone())
+    pXb, Res = m.backward(pYb)
+    b.put("bw_invSigma", pXb.invSigma)
+    b.put("bw_invSigmamu", pXb.invSigmamu)
+    b.put("bw_Res", Res)
+    shared_Py = rand_spd((), n, gen)
+    b.put("bws_in_invSigma", shared_Py)
+    pYbs = dists.MultivariateNormal_vector_format(invSigma=shared_Py.clone(), invSigmamu=py_eta.clone())
+    pXbs, Res = m.backward(pYbs, Res=0.25)
+    b.put("bws_invSigma", pXbs.invSigma)
+    b.put("bws_invSigmamu", pXbs.invSigmamu)
+    b.put("bws_Res", Res)
+
+    pYq = dists.MultivariateNormal_vector_format(invSigma=py_P.clone(), invSigmamu=py_eta.clone())
+    pxo, Res = m.Elog_like_X_given_pY(pYq)
+    b.put("ELXpY_invSigma", pxo.invSigma)
+    b.put("ELXpY_invSigmamu", pxo.invSigmamu)
+    b.put("ELXpY_mu", pxo.mu)
+    b.put("ELXpY_Sigma", pxo.Sigma)
+    b.put("ELXpY_Res", Res)
+
+    # update(pX, pY, p) with distributions: pX = MVN_vf (per-sample cov), pY = Delta(Y)
+    ux_Sigma = rand_spd((N,) + (1,) * nb, p - (1 if pad_X else 0) if False else m.p - (1 if pad_X else 0), gen)
+    ux_mu = torch.randn((N,) + (1,) * nb + (m.p - (1 if pad_X else 0), 1), generator=gen)
+    b.put("upd_x_mu", ux_mu)
+    b.put("upd_x_Sigma", ux_Sigma)
+    pXu = dists.MultivariateNormal_vector_format(mu=ux_mu.expand((N,) + batch + ux_mu.shape[-2:]).clone(),
+                                                 Sigma=ux_Sigma.expand((N,) + batch + ux_Sigma.shape[-2:]).clone())
+    b.put("ELpXpY", m.Elog_like_given_pX_pY(pXu, dists.Delta(Y)))
+    m.update(pXu, dists.Delta(Y), p=pr, lr=0.8)
+    snap_mnw(b, m, "upd_")
+    # also a Gaussian pY
+    uy_Sigma = rand_spd((N,) + (1,) * nb, n, gen) * 0.1
+    b.put("upd_y_Sigma", uy_Sigma)
+    pYu = dists.MultivariateNormal_vector_format(mu=Y.clone(), Sigma=uy_Sigma.expand((N,) + batch + (n, n)).clone())
+    m.update(pXu, pYu, p=pr, lr=1.0, beta=0.5)
+    snap_mnw(b, m, "upd2_")
+    m.update(pXu, pYu, p=pr, lr=1.0, beta=0.5)
+    snap_mnw(b, m, "upd3_")
+    b.put("KLqprior_end", m.KLqprior())
+
+
+def gen_mnw():
+    b = Book()
+    gen = torch.Generator().manual_seed(505)
+    mnw_case(b, "mnw_4x3_b5", 4, 3, (5,), False, gen)
+    mnw_case(b, "mnw_4x3_b5_pad", 4, 3, (5,), True, gen)
+    mnw_case(b, "mnw_4x3_nobatch", 4, 3, (), False, gen)
+    mnw_case(b, "mnw_32x32", 32, 32, (), False, gen, N=6)
+    mnw_case(b, "mnw_6x7_b2_pad", 6, 7, (2,), True, gen)
+    # masks (shared by the batch)
+    X_mask = (torch.rand(1, 3, generator=gen) > 0.3)
+    X_mask[..., 0] = True
+    mnw_mask_case(b, "mnw_Xmask", 4, 3, (5,), False, gen, X_mask=X_mask)
+    mask = torch.rand(4, 3, generator=gen) > 0.3
+    mask[0, 0] = True
+    mnw_mask_case(b, "mnw_mask", 4, 3, (5,), False, gen, mask=mask)
+    mnw_mask_case(b, "mnw_mask_pad", 4, 3, (5,), True, gen, mask=mask)
+    b.save("mnw")
+
+
+def mnw_mask_case(b, name, n, p, batch, pad_X, gen, mask=None, X_mask=None, N=24):
+    b.begin(name)
+    m = transforms.MatrixNormalWishart(event_shape=(n, p), batch_shape=batch, pad_X=pad_X,
+                                       mask=None if mask is None else mask.clone(),
+                                       X_mask=None if X_mask is None else X_mask.clone())
+    b.put("n", n)
+    b.put("p", p)
+    b.put("pad_X", int(pad_X))
+    b.put("batch_shape", np.array(batch, dtype=np.int64))
+    if mask is not None:
+        b.put("mask", mask)
+    if X_mask is not None:
+        b.put("X_mask", X_mask)
+    snap_mnw(b, m, "init_")
+    b.put("init_mu_0", m.mu_0)
+    W = torch.randn(batch + (n, p), generator=gen)
+    X = torch.randn((N,) + (1,) * len(batch) + (p, 1), generator=gen)
+    Y = W @ X + 0.3 * torch.randn((N,) + batch + (n, 1), generator=gen)
+    pr = torch.softmax(torch.randn((N,) + batch, generator=gen), -1)
+    b.put("X", X)
+    b.put("Y", Y)
+    b.put("p_resp", pr)
+    Xe = X.expand((N,) + batch + (p, 1))
+    m.raw_update(Xe, Y, p=pr, lr=1.0)
+    snap_mnw(b, m, "raw1_")
+    m.raw_update(Xe, Y, p=pr, lr=0.5)
+    snap_mnw(b, m, "raw2_")
+    b.put("KLqprior", m.KLqprior())
+    b.put("Elog_like", m.Elog_like(X, Y))
+
+
+# ---------------------------------------------------------------------- GMM
+def two_moons(n, gen, noise=0.08):
+    """Our own two-interleaved-half-circles generator (shape of examples/two_moons.py data)."""
+    t = torch.rand(n, generator=gen) * np.pi
+    half = torch.arange(n) % 2
+    x = torch.where(half == 0, torch.cos(t), 1.0 - torch.cos(t))
+    y = torch.where(half == 0, torch.sin(t), 0.5 - torch.sin(t))
+    return torch.stack((x, y), -1) + noise * torch.randn(n, 2, generator=gen)
+
+
+def gen_gmm():
+    import models  # reference
+
+    b = Book()
+    gen = torch.Generator().manual_seed(606)
+    b.begin("gmm_k4_d2")
+    data = two_moons(400, gen)
+    b.put("data", data)
+    torch.manual_seed(7)
+    g = models.GaussianMixtureModel(4, 2)
+    idx = torch.randint(400, (4,), generator=gen)
+    g.dist.mu = data[idx, :].clone()
+    b.put("init_mu", g.dist.mu)
+    b.put("init_alpha", g.pi.alpha)
+    b.put("alpha_0", g.pi.alpha_0)
+    b.put("init_invU_0", g.dist.invU.invU_0)
+    for it in range(1, 21):
+        g.update(data, iters=1, lr=1.0, verbose=False)
+        if it in (1, 2, 5, 20):
+            pre = f"it{it}_"
+            b.put(pre + "p", g.p)
+            b.put(pre + "NA", g.NA)
+            b.put(pre + "logZ", g.logZ)
+            b.put(pre + "ELBO", g.ELBO_last)
+            b.put(pre + "alpha", g.pi.alpha)
+            snap_niw(b, g.dist, pre)
+    b.put("final_assignment", g.assignment())
+    b.put("final_KLqprior", g.KLqprior())
+
+    # generic Mixture with non-trivial batch/event shapes (reference tests/test_dists.py shape)
+    b.begin("mixture_b3_k6_e32")
+    torch.manual_seed(8)
+    niw = dists.NormalInverseWishart(event_shape=(3, 2), batch_shape=(3, 6))
+    mix = dists.Mixture(niw, event_shape=(6,))
+    X = torch.randn(50, 3, 3, 2, generator=gen) + torch.randn(1, 3, 3, 2, generator=gen)
+    b.put("X", X)
+    b.put("init_mu", niw.mu)
+    b.put("init_alpha", mix.pi.alpha)
+    for it in (1, 2, 3):
+        mix.update(X, iters=1, lr=0.9)
+        pre = f"it{it}_"
+        b.put(pre + "p", mix.p)
+        b.put(pre + "NA", mix.NA)
+        b.put(pre + "logZ", mix.logZ)
+        b.put(pre + "ELBO", mix.ELBO_last)
+        b.put(pre + "alpha", mix.pi.alpha)
+        snap_niw(b, mix.dist, pre)
+    b.save("gmm")
+
+
+GROUPS = {"wishart": gen_wishart, "niw": gen_niw, "mvn": gen_mvn, "matrix_utils": gen_matrix_utils,
+          "mnw": gen_mnw, "gmm": gen_gmm}
+
+if __name__ == "__main__":
+    want = sys.argv[1:] or list(GROUPS)
+    for g in want:
+        GROUPS[g]()
