@@ -1,0 +1,118 @@
+/* libvbmp_hip.so -- C ABI of the MI355X (gfx950) conjugate-update kernels.
+ *
+ * This is the drop-in boundary for the hot path of bayesianempirimancer/pyVBMP (reference paths are
+ * relative to the reference repo root).  The reference has no FFI: its boundary is the duck-typed
+ * Python method surface (ss_update / raw_update / Elog_like / forward / backward ...).  Each entry
+ * point below replaces the tensor arithmetic inside one of those methods; the Python classes in
+ * pyvbmp_amd/ keep the reference's names and signatures and call these through ctypes
+ * (see INTEGRATION.md for the stub a reference maintainer would add).
+ *
+ * Conventions (all entry points)
+ *   - every pointer is a DEVICE pointer; `stream` is a hipStream_t (NULL = default stream);
+ *   - the call only enqueues work on `stream`: no allocation, no synchronisation, no global
+ *     state, re-entrant; the caller owns every buffer and keeps it alive until the stream passes;
+ *   - batch layout: B independent problems; a D x D matrix is row-major contiguous, a D-vector is
+ *     contiguous; `s*` arguments are the distance in ELEMENTS between consecutive batch entries of
+ *     that operand.  Stride 0 is allowed for read-only operands (one shared value, the
+ *     reference's stride-0 expanded priors, dists/Wishart.py:17-18);
+ *   - outputs are dense (stride D*D, D or 1);
+ *   - 1 <= D <= VBMP_MAX_DIM (64); `_f64` = double, `_f32` = float;
+ *   - `nonspd` (nullable) is a device int32 that is atomically incremented once per matrix whose
+ *     elimination met a non-positive pivot.  Outputs for such a matrix follow the reference's
+ *     silent behaviour: logdet is NaN when det < 0 (Tensor.logdet), the inverse is still the
+ *     algebraic inverse;
+ *   - return value: 0 = enqueued, VBMP_ERR_ARG (-1) = bad argument, VBMP_ERR_LAUNCH (-2) = HIP
+ *     launch failure.
+ */
+#ifndef VBMP_HIP_H
+#define VBMP_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VBMP_ABI_VERSION 1
+int vbmp_abi_version(void);
+
+/* K1 -- Ainv = A^-1 and logdet = log det A of B symmetric positive definite matrices.
+ * Replaces every `X.inverse()` + `X.logdet()` pair on the path: dists/Wishart.py:20-24,55-56;
+ * dists/MultivariateNormal.py:35-59; dists/MultivariateNormal_vector_format.py:79-107;
+ * utils/matrix_utils.py:11-55; transforms/MatrixNormalWishart.py:46-48,134-135.
+ * logdet may be NULL. */
+int vbmp_spd_inv_logdet_f64(const double* A, int64_t sA, double* Ainv, double* logdet, int64_t B, int D,
+                            int* nonspd, void* stream);
+int vbmp_spd_inv_logdet_f32(const float* A, int64_t sA, float* Ainv, float* logdet, int64_t B, int D,
+                            int* nonspd, void* stream);
+
+/* K2a -- Wishart.ss_update (dists/Wishart.py:53-56), beta handled by the caller:
+ *   invU = lr*(invU0 + SExx) + (1-lr)*invU_old ; nu = lr*(nu0 + N) + (1-lr)*nu_old ;
+ *   U = invU^-1 ; logdet = log det invU.
+ * invU_old / nu_old are read only when lr != 1 (may be NULL otherwise) and may alias nothing
+ * that is written. */
+int vbmp_wishart_ss_update_f64(const double* SExx, int64_t sSExx, const double* N, int64_t sN, const double* invU0,
+                               int64_t sinvU0, const double* nu0, int64_t snu0, const double* invU_old,
+                               int64_t sinvU_old, const double* nu_old, int64_t snu_old, double lr, double* invU,
+                               double* nu, double* U, double* logdet, int64_t B, int D, int* nonspd, void* stream);
+int vbmp_wishart_ss_update_f32(const float* SExx, int64_t sSExx, const float* N, int64_t sN, const float* invU0,
+                               int64_t sinvU0, const float* nu0, int64_t snu0, const float* invU_old,
+                               int64_t sinvU_old, const float* nu_old, int64_t snu_old, float lr, float* invU,
+                               float* nu, float* U, float* logdet, int64_t B, int D, int* nonspd, void* stream);
+
+/* K2 -- NormalInverseWishart.ss_update (dists/NormalInverseWishart.py:61-68 fused with
+ * dists/Wishart.py:53-56); the headline operation (BASELINE.json config 2).  Per batch element:
+ *   lam* = lam0 + N ; mu* = (lam0*mu0 + SEx)/lam* ;
+ *   W    = SExx + lam0 mu0 mu0^T - lam* mu* mu*^T            (un-blended lam*, mu*: NIW.py:61-63)
+ *   lam  = lr*lam* + (1-lr)*lam_old ; mu = lr*mu* + (1-lr)*mu_old
+ *   invU = lr*(invU0 + W) + (1-lr)*invU_old ; nu = lr*(nu0 + N) + (1-lr)*nu_old
+ *   U = invU^-1 ; logdet = log det invU          (skipped when fixed_precision != 0, NIW.py:67)
+ * *_old are read only when lr != 1. */
+int vbmp_niw_ss_update_f64(const double* SExx, int64_t sSExx, const double* SEx, int64_t sSEx, const double* N,
+                           int64_t sN, const double* lam0, int64_t slam0, const double* mu0, int64_t smu0,
+                           const double* invU0, int64_t sinvU0, const double* nu0, int64_t snu0,
+                           const double* lam_old, int64_t slam_old, const double* mu_old, int64_t smu_old,
+                           const double* invU_old, int64_t sinvU_old, const double* nu_old, int64_t snu_old,
+                           double lr, double* lam, double* mu, double* invU, double* nu, double* U, double* logdet,
+                           int64_t B, int D, int fixed_precision, int* nonspd, void* stream);
+int vbmp_niw_ss_update_f32(const float* SExx, int64_t sSExx, const float* SEx, int64_t sSEx, const float* N,
+                           int64_t sN, const float* lam0, int64_t slam0, const float* mu0, int64_t smu0,
+                           const float* invU0, int64_t sinvU0, const float* nu0, int64_t snu0, const float* lam_old,
+                           int64_t slam_old, const float* mu_old, int64_t smu_old, const float* invU_old,
+                           int64_t sinvU_old, const float* nu_old, int64_t snu_old, float lr, float* lam, float* mu,
+                           float* invU, float* nu, float* U, float* logdet, int64_t B, int D, int fixed_precision,
+                           int* nonspd, void* stream);
+
+/* K3a -- expected Gaussian log-likelihood as a quadratic form (the body of
+ * NormalInverseWishart.Elog_like, dists/NormalInverseWishart.py:91-97, without the (N,K,D,D)
+ * temporary):   out[s,bo,bi] = -1/2 x^T P x + x^T b + c,   x = X[s,bi,:],  (P,b,c) = component (bo,bi).
+ * X is dense (S,Bi,D); P (Bo*Bi,D,D), b (Bo*Bi,D), c (Bo*Bi) dense; out dense (S,Bo,Bi).
+ * Bi = 1 is the mixture case (every component sees the same sample). */
+int vbmp_quadform_loglike_f64(const double* X, int64_t S, int64_t Bo, int64_t Bi, int D, const double* P,
+                              const double* b, const double* c, double* out, void* stream);
+int vbmp_quadform_loglike_f32(const float* X, int64_t S, int64_t Bo, int64_t Bi, int D, const float* P,
+                              const float* b, const float* c, float* out, void* stream);
+
+/* K3 -- fused mixture E-step (Mixture.update_assignments, dists/Mixture.py:38-45, with the NIW
+ * likelihood inlined): l[s,k] = quadratic form above with c[k] already holding E log pi_k;
+ * p[s,k] = softmax_k l[s,k];  NA[k] += sum_s p[s,k];  logZ[0] += sum_s logsumexp_k l[s,k].
+ * X dense (S,D); p dense (S,K) (also used as scratch); NA (K) and logZ (1) MUST be zeroed by the caller
+ * (they are accumulated with atomics, so their last bits depend on arrival order). */
+int vbmp_mixture_estep_f64(const double* X, int64_t S, int K, int D, const double* P, const double* b,
+                           const double* c, double* p, double* NA, double* logZ, void* stream);
+int vbmp_mixture_estep_f32(const float* X, int64_t S, int K, int D, const float* P, const float* b, const float* c,
+                           float* p, float* NA, float* logZ, void* stream);
+
+/* K4 -- weighted sufficient statistics (NormalInverseWishart.raw_update, dists/NormalInverseWishart.py:72-84;
+ * MultivariateNormal.raw_update, dists/MultivariateNormal.py:93-99) without the (N,K,D,D) temporary:
+ *   Nk[bo,bi] += sum_s w;  SEx[bo,bi,:] += sum_s w x;  SExx[bo,bi,:,:] += sum_s w x x^T,
+ *   x = X[s,bi,:] (dense (S,Bi,D)),  w = p[s,bo,bi] (dense (S,Bo,Bi); NULL = all ones).
+ * Outputs MUST be zeroed by the caller (atomic accumulation).  Bi <= 65535. */
+int vbmp_weighted_moments_f64(const double* X, const double* p, int64_t S, int64_t Bo, int64_t Bi, int D, double* Nk,
+                              double* SEx, double* SExx, void* stream);
+int vbmp_weighted_moments_f32(const float* X, const float* p, int64_t S, int64_t Bo, int64_t Bi, int D, float* Nk,
+                              float* SEx, float* SExx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VBMP_HIP_H */

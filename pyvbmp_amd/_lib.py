@@ -1,0 +1,127 @@
+"""ctypes binding of libvbmp_hip.so (the C-ABI declared in include/vbmp_hip.h).
+
+There is deliberately no fallback: if the shared library is missing or a tensor does not live on a
+HIP device, the call raises.  Build the library with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C pyvbmp_amd/csrc`.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvbmp_hip.so")
+
+_c_i64 = ctypes.c_int64
+_c_int = ctypes.c_int
+_c_ptr = ctypes.c_void_p
+
+ABI_VERSION = 1
+
+_lib = None
+
+
+class VbmpHipError(RuntimeError):
+    pass
+
+
+def _sig_spd(T):
+    return [_c_ptr, _c_i64, _c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr]
+
+
+def _sig_wishart(T):
+    return [_c_ptr, _c_i64] * 6 + [T] + [_c_ptr] * 4 + [_c_i64, _c_int, _c_ptr, _c_ptr]
+
+
+def _sig_niw(T):
+    return [_c_ptr, _c_i64] * 11 + [T] + [_c_ptr] * 6 + [_c_i64, _c_int, _c_int, _c_ptr, _c_ptr]
+
+
+def _sig_quadform(T):
+    # X, S, Bo, Bi, D, P, b, c, out, stream
+    return [_c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr]
+
+
+def _sig_estep(T):
+    # X, S, K, D, P, b, c, p, NA, logZ, stream
+    return [_c_ptr, _c_i64, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr]
+
+
+def _sig_wmom(T):
+    # X, p, S, Bo, Bi, D, Nk, SEx, SExx, stream
+    return [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr]
+
+
+# symbol -> argtypes builder.  Every symbol declared in include/vbmp_hip.h appears here
+# (tests/test_cabi.py cross-checks the header against this table and against the .so).
+SYMBOLS = {
+    "vbmp_spd_inv_logdet": _sig_spd,
+    "vbmp_wishart_ss_update": _sig_wishart,
+    "vbmp_niw_ss_update": _sig_niw,
+    "vbmp_quadform_loglike": _sig_quadform,
+    "vbmp_mixture_estep": _sig_estep,
+    "vbmp_weighted_moments": _sig_wmom,
+}
+DTYPES = {"f64": (torch.float64, ctypes.c_double), "f32": (torch.float32, ctypes.c_float)}
+
+
+def load():
+    """Load (once) and return the ctypes library; raise loudly when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VbmpHipError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `make -C {os.path.join(_HERE, 'csrc')}` "
+            "(hipcc --offload-arch=gfx950). pyvbmp_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.vbmp_abi_version.restype = _c_int
+    lib.vbmp_abi_version.argtypes = []
+    v = lib.vbmp_abi_version()
+    if v != ABI_VERSION:
+        raise VbmpHipError(f"libvbmp_hip.so ABI {v} != expected {ABI_VERSION}; rebuild it")
+    for base, sig in SYMBOLS.items():
+        for suf, (_, cT) in DTYPES.items():
+            fn = getattr(lib, f"{base}_{suf}")
+            fn.restype = _c_int
+            fn.argtypes = sig(cT)
+    _lib = lib
+    return lib
+
+
+def suffix(dtype):
+    if dtype == torch.float64:
+        return "f64"
+    if dtype == torch.float32:
+        return "f32"
+    raise VbmpHipError(f"unsupported dtype {dtype}: the HIP path computes in float32 or float64")
+
+
+def require_device(*tensors):
+    """All tensors must be on the same HIP device (torch calls it 'cuda')."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise VbmpHipError("pyvbmp_amd needs tensors on a HIP device (got a CPU tensor); "
+                               "there is no CPU path - use torch.set_default_device('cuda') or device='cuda'")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise VbmpHipError(f"tensors on different devices: {dev} vs {t.device}")
+    return dev
+
+
+def stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def check(rc, name):
+    if rc != 0:
+        raise VbmpHipError(f"{name} failed with code {rc} "
+                           f"({'bad argument' if rc == -1 else 'HIP launch failure' if rc == -2 else 'unknown'})")

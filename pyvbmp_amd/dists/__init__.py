@@ -1,0 +1,4 @@
+"""Distribution nodes.  As in the reference (dists/__init__.py:1-18) each class is re-exported under
+the name of its submodule, so `import pyvbmp_amd.dists.Wishart as Wishart` yields the class."""
+from .Wishart import Wishart
+from .NormalInverseWishart import NormalInverseWishart

@@ -1,0 +1,229 @@
+"""Tensor-level entry points: shape/stride marshalling around the C-ABI kernels.
+
+Everything here takes torch tensors that already live on the HIP device, flattens the leading
+batch dims, turns broadcast (stride-0 expanded) operands into stride-0 kernel arguments instead of
+materialising them, allocates the outputs and enqueues ONE kernel on the current stream.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib as L
+
+
+def _prod(shape):
+    return int(math.prod(shape))
+
+
+def batch_operand(t, batch_shape, inner_shape):
+    """Return (tensor, element stride between batch entries) for an operand that is broadcastable
+    to batch_shape + inner_shape.  Fully shared operands (every batch stride 0, dense inner block)
+    are passed as stride 0; everything else is made dense."""
+    full = tuple(batch_shape) + tuple(inner_shape)
+    ni = len(inner_shape)
+    if t.ndim < len(full):
+        t = t.reshape((1,) * (len(full) - t.ndim) + tuple(t.shape))
+    if tuple(t.shape) != full:
+        t = t.expand(full)
+    nb = len(batch_shape)
+    inner_dense = t[(0,) * nb].is_contiguous() if (nb and _prod(batch_shape) > 0) else t.is_contiguous()
+    shared = all(t.stride(i) == 0 or t.shape[i] == 1 for i in range(nb))
+    if shared and inner_dense and nb > 0:
+        return t, 0
+    t = t.contiguous()
+    return t, _prod(inner_shape)
+
+
+def spd_inv_logdet(A, want_logdet=True, nonspd=None):
+    """(A^-1, log det A) for a (..., D, D) stack of SPD matrices.  One K1 launch."""
+    dev = L.require_device(A)
+    lib = L.load()
+    D = A.shape[-1]
+    assert A.shape[-2] == D
+    bshape = tuple(A.shape[:-2])
+    B = _prod(bshape)
+    Ac = A.contiguous()
+    Ainv = torch.empty_like(Ac)
+    logdet = torch.empty(bshape, dtype=A.dtype, device=dev) if want_logdet else None
+    if B > 0:
+        fn = getattr(lib, "vbmp_spd_inv_logdet_" + L.suffix(A.dtype))
+        L.check(fn(L.ptr(Ac), D * D, L.ptr(Ainv), L.ptr(logdet), B, D, L.ptr(nonspd), L.stream_ptr(dev)),
+                "vbmp_spd_inv_logdet")
+    return Ainv, logdet
+
+
+def spd_inverse(A):
+    return spd_inv_logdet(A, want_logdet=False)[0]
+
+
+def wishart_ss_update(SExx, N, invU0, nu0, invU_old, nu_old, lr, nonspd=None):
+    """K2a.  SExx: batch+(D,D); N: batch.  Returns (invU, nu, U, logdet) dense, shaped like SExx / N."""
+    dev = L.require_device(SExx, N, invU0, nu0)
+    lib = L.load()
+    D = SExx.shape[-1]
+    bshape = tuple(SExx.shape[:-2])
+    B = _prod(bshape)
+    dt = SExx.dtype
+    SExx_c, sS = batch_operand(SExx, bshape, (D, D))
+    N_c, sN = batch_operand(N.to(dt), bshape, ())
+    i0, si0 = batch_operand(invU0.to(dt), bshape, (D, D))
+    n0, sn0 = batch_operand(nu0.to(dt), bshape, ())
+    blend = float(lr) != 1.0
+    if blend:
+        io, sio = batch_operand(invU_old.to(dt), bshape, (D, D))
+        no, sno = batch_operand(nu_old.to(dt), bshape, ())
+    else:
+        io = no = None
+        sio = sno = 0
+    invU = torch.empty(bshape + (D, D), dtype=dt, device=dev)
+    U = torch.empty_like(invU)
+    nu = torch.empty(bshape, dtype=dt, device=dev)
+    logdet = torch.empty(bshape, dtype=dt, device=dev)
+    if B > 0:
+        suf = L.suffix(dt)
+        fn = getattr(lib, "vbmp_wishart_ss_update_" + suf)
+        cT = L.DTYPES[suf][1]
+        L.check(fn(L.ptr(SExx_c), sS, L.ptr(N_c), sN, L.ptr(i0), si0, L.ptr(n0), sn0, L.ptr(io), sio, L.ptr(no), sno,
+                   cT(float(lr)), L.ptr(invU), L.ptr(nu), L.ptr(U), L.ptr(logdet), B, D, L.ptr(nonspd),
+                   L.stream_ptr(dev)), "vbmp_wishart_ss_update")
+    return invU, nu, U, logdet
+
+
+def niw_ss_update(SExx, SEx, N, lam0, mu0, invU0, nu0, lam_old, mu_old, invU_old, nu_old, lr, fixed_precision=False,
+                  nonspd=None):
+    """K2 (headline op).  SExx: batch+(D,D); SEx: batch+(D,); N, lam*: batch.
+    Returns (lam, mu, invU, nu, U, logdet); the last four are None when fixed_precision."""
+    dev = L.require_device(SExx, SEx, N, lam0, mu0, invU0, nu0)
+    lib = L.load()
+    D = SExx.shape[-1]
+    bshape = tuple(SExx.shape[:-2])
+    B = _prod(bshape)
+    dt = SExx.dtype
+    SExx_c, sS = batch_operand(SExx, bshape, (D, D))
+    SEx_c, sx = batch_operand(SEx.to(dt), bshape, (D,))
+    N_c, sN = batch_operand(N.to(dt), bshape, ())
+    l0, sl0 = batch_operand(lam0.to(dt), bshape, ())
+    m0, sm0 = batch_operand(mu0.to(dt), bshape, (D,))
+    i0, si0 = batch_operand(invU0.to(dt), bshape, (D, D))
+    n0, sn0 = batch_operand(nu0.to(dt), bshape, ())
+    blend = float(lr) != 1.0
+    lo = mo = io = no = None
+    slo = smo = sio = sno = 0
+    if blend:
+        lo, slo = batch_operand(lam_old.to(dt), bshape, ())
+        mo, smo = batch_operand(mu_old.to(dt), bshape, (D,))
+        if not fixed_precision:
+            io, sio = batch_operand(invU_old.to(dt), bshape, (D, D))
+            no, sno = batch_operand(nu_old.to(dt), bshape, ())
+    lam = torch.empty(bshape, dtype=dt, device=dev)
+    mu = torch.empty(bshape + (D,), dtype=dt, device=dev)
+    if fixed_precision:
+        invU = U = nu = logdet = None
+    else:
+        invU = torch.empty(bshape + (D, D), dtype=dt, device=dev)
+        U = torch.empty_like(invU)
+        nu = torch.empty(bshape, dtype=dt, device=dev)
+        logdet = torch.empty(bshape, dtype=dt, device=dev)
+    if B > 0:
+        suf = L.suffix(dt)
+        fn = getattr(lib, "vbmp_niw_ss_update_" + suf)
+        cT = L.DTYPES[suf][1]
+        L.check(fn(L.ptr(SExx_c), sS, L.ptr(SEx_c), sx, L.ptr(N_c), sN, L.ptr(l0), sl0, L.ptr(m0), sm0, L.ptr(i0), si0,
+                   L.ptr(n0), sn0, L.ptr(lo), slo, L.ptr(mo), smo, L.ptr(io), sio, L.ptr(no), sno, cT(float(lr)),
+                   L.ptr(lam), L.ptr(mu), L.ptr(invU), L.ptr(nu), L.ptr(U), L.ptr(logdet), B, D,
+                   1 if fixed_precision else 0, L.ptr(nonspd), L.stream_ptr(dev)), "vbmp_niw_ss_update")
+    return lam, mu, invU, nu, U, logdet
+
+
+def _split_components(x_comp_shape, mat_batch):
+    """X carries one axis per component axis, each of size 1 (broadcast) or full.  Return k such that
+    axes [:k] are broadcast ("outer": every outer component sees the same sample) and axes [k:] are
+    dense ("inner"); None when the pattern is mixed and X has to be materialised."""
+    k = 0
+    n = len(mat_batch)
+    while k < n and x_comp_shape[k] == 1:
+        k += 1
+    if tuple(x_comp_shape[k:]) != tuple(mat_batch[k:]):
+        return None
+    return k
+
+
+def _dense_samples(X, mat_batch, D):
+    """X: sample + comp* + (D,) -> (X2 dense (S,Bi,D), sample_shape, Bo, Bi)."""
+    nb = len(mat_batch)
+    sample_shape = tuple(X.shape[:X.ndim - nb - 1])
+    comp = tuple(X.shape[X.ndim - nb - 1:-1])
+    k = _split_components(comp, mat_batch)
+    if k is None:
+        X = X.expand(sample_shape + tuple(mat_batch) + (D,))
+        k = 0
+    S, Bo, Bi = _prod(sample_shape), _prod(mat_batch[:k]), _prod(mat_batch[k:])
+    return X.reshape(S, Bi, D).contiguous(), sample_shape, Bo, Bi
+
+
+def quadform_loglike(X, P, b, c):
+    """K3a: -1/2 x^T P x + x^T b + c for every (sample, component).
+    X: sample + comp* + (D,), comp* broadcastable to c.shape; P: c.shape+(D,D); b: c.shape+(D,)."""
+    dev = L.require_device(X, P, b, c)
+    lib = L.load()
+    D = P.shape[-1]
+    mat_batch = tuple(c.shape)
+    dt = P.dtype
+    X2, sample_shape, Bo, Bi = _dense_samples(X.to(dt), mat_batch, D)
+    S = X2.shape[0]
+    Pc = P.expand(mat_batch + (D, D)).contiguous()
+    bc = b.expand(mat_batch + (D,)).contiguous()
+    cc = c.contiguous()
+    out = torch.empty((S, Bo, Bi), dtype=dt, device=dev)
+    if out.numel() > 0:
+        fn = getattr(lib, "vbmp_quadform_loglike_" + L.suffix(dt))
+        L.check(fn(L.ptr(X2), S, Bo, Bi, D, L.ptr(Pc), L.ptr(bc), L.ptr(cc), L.ptr(out), L.stream_ptr(dev)),
+                "vbmp_quadform_loglike")
+    return out.reshape(sample_shape + mat_batch)
+
+
+def mixture_estep(X, P, b, c):
+    """K3: fused responsibilities for a K-component mixture over dense samples X (S,D).
+    c must already include E log pi.  Returns p (S,K), NA (K), logZ ()."""
+    dev = L.require_device(X, P, b, c)
+    lib = L.load()
+    K, D = P.shape[0], P.shape[-1]
+    dt = P.dtype
+    Xc = X.to(dt).contiguous()
+    S = Xc.shape[0]
+    p = torch.empty((S, K), dtype=dt, device=dev)
+    acc = torch.zeros(K + 1, dtype=dt, device=dev)
+    if S > 0:
+        fn = getattr(lib, "vbmp_mixture_estep_" + L.suffix(dt))
+        L.check(fn(L.ptr(Xc), S, K, D, L.ptr(P.contiguous()), L.ptr(b.contiguous()), L.ptr(c.contiguous()), L.ptr(p),
+                   L.ptr(acc), ctypes.c_void_p(acc.data_ptr() + K * acc.element_size()), L.stream_ptr(dev)),
+                "vbmp_mixture_estep")
+    return p, acc[:K], acc[K]
+
+
+def weighted_moments(X, pv, n_sample_dims, mat_batch):
+    """K4: N = sum w, SEx = sum w x, SExx = sum w x x^T over the sample axes.
+    X: sample + comp* + (D,); pv: sample + (axes broadcastable to mat_batch) or None (unit weights)."""
+    dev = L.require_device(X, pv)
+    lib = L.load()
+    D = X.shape[-1]
+    mat_batch = tuple(mat_batch)
+    dt = X.dtype
+    if pv is None:
+        sample_shape = tuple(X.shape[:n_sample_dims])
+        X = X.expand(sample_shape + mat_batch + (D,))
+    X2, sample_shape, Bo, Bi = _dense_samples(X, mat_batch, D)
+    assert len(sample_shape) == n_sample_dims
+    S = X2.shape[0]
+    p2 = None
+    if pv is not None:
+        p2 = pv.to(dt).expand(sample_shape + mat_batch).reshape(S, Bo, Bi).contiguous()
+    nB = Bo * Bi
+    buf = torch.zeros(nB * (1 + D + D * D), dtype=dt, device=dev)
+    Nk, SEx, SExx = buf[:nB], buf[nB:nB * (1 + D)], buf[nB * (1 + D):]
+    if S > 0 and nB > 0:
+        fn = getattr(lib, "vbmp_weighted_moments_" + L.suffix(dt))
+        L.check(fn(L.ptr(X2), L.ptr(p2), S, Bo, Bi, D, L.ptr(Nk), L.ptr(SEx), L.ptr(SExx), L.stream_ptr(dev)),
+                "vbmp_weighted_moments")
+    return Nk.reshape(mat_batch), SEx.reshape(mat_batch + (D,)), SExx.reshape(mat_batch + (D, D))
