@@ -14,7 +14,9 @@ def resolve(device=None, dtype=None):
 
 def as_param(v, device, dtype):
     """scalar / tensor prior parameter -> tensor on (device, dtype)"""
-    return torch.as_tensor(v).to(device=device, dtype=dtype)
+    if isinstance(v, torch.Tensor):
+        return v.to(device=device, dtype=dtype)
+    return torch.as_tensor(v, dtype=dtype, device=device)  # python scalars: no detour through float32
 
 
 def trailing(v, k):

@@ -116,14 +116,18 @@ class NormalInverseWishart():
     # ------------------------------------------------------------------ likelihood / ELBO
     def Elog_like(self, X):
         """E_q[log N(X | mu, Sigma)] per (sample, batch); extra event dims are summed (ref :91-97)."""
-        W = self.invU
-        P = W.EinvSigma()
-        b = self.EinvSigmamu()
-        c = -0.5 * self.EXTinvUX() + 0.5 * W.ElogdetinvSigma() - 0.5 * self.dim * _LOG2PI
+        P, b, c = self.mixture_estep_params()
         out = ops.quadform_loglike(X, P, b, c)
         for i in range(self.event_dim - 1):
             out = out.sum(-1)
         return out
+
+    def mixture_estep_params(self):
+        """(P, b, c) of the quadratic form  -1/2 x^T P x + x^T b + c  = Elog_like(x), per component
+        (fed to the fused mixture E-step kernel K3)."""
+        W = self.invU
+        c = -0.5 * self.EXTinvUX() + 0.5 * W.ElogdetinvSigma() - 0.5 * self.dim * _LOG2PI
+        return W.EinvSigma(), self.EinvSigmamu(), c
 
     def KLqprior(self):
         d = self.mu - self.mu_0

@@ -1,4 +1,7 @@
 """Distribution nodes.  As in the reference (dists/__init__.py:1-18) each class is re-exported under
 the name of its submodule, so `import pyvbmp_amd.dists.Wishart as Wishart` yields the class."""
-from .Wishart import Wishart
+from .Delta import Delta
+from .Dirichlet import Dirichlet
+from .Mixture import Mixture
 from .NormalInverseWishart import NormalInverseWishart
+from .Wishart import Wishart

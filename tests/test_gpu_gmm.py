@@ -1,0 +1,107 @@
+"""GPU parity of the mixture path (K3 fused E-step, K3a quadratic log-likelihood, K4 weighted moments,
+then K2) through Mixture / GaussianMixtureModel, against golden fixtures captured from the reference
+(BASELINE configs[0]: GMM K=4, D=2 on two-moons data) and against the CPU oracle at larger sizes."""
+import pytest
+import torch
+
+from tests.helpers import TOL32, TOL64, assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_gmm_two_moons_golden(golden):
+    from pyvbmp_amd.models import GaussianMixtureModel
+    c = golden("gmm")["gmm_k4_d2"]
+    g = GaussianMixtureModel(4, 2, device=DEV, dtype=torch.float64)
+    g.dist.mu = c["init_mu"].to(DEV)
+    g.pi.alpha = c["init_alpha"].to(DEV)
+    assert_close(g.pi.alpha_0, c["alpha_0"])
+    assert_close(g.dist.invU.invU_0, c["init_invU_0"])
+    X = c["data"].to(DEV)
+    for it in range(1, 21):
+        g.update(X, iters=1, lr=1.0)
+        if it in (1, 2, 5, 20):
+            pre = f"it{it}_"
+            tol = TOL64 if it <= 2 else 1e-8  # EM iterations amplify rounding differences
+            assert_close(g.p, c[pre + "p"], tol, what=pre + "p")
+            assert_close(g.NA, c[pre + "NA"], tol, what=pre + "NA")
+            assert_close(g.logZ, c[pre + "logZ"], tol, what=pre + "logZ")
+            assert_close(g.ELBO_last, c[pre + "ELBO"], tol, what=pre + "ELBO")
+            assert_close(g.pi.alpha, c[pre + "alpha"], tol, what=pre + "alpha")
+            assert_close(g.dist.mu, c[pre + "mu"], tol, what=pre + "mu")
+            assert_close(g.dist.lambda_mu, c[pre + "lambda_mu"], tol, what=pre + "lambda")
+            assert_close(g.dist.invU.invU, c[pre + "invU"], tol, what=pre + "invU")
+            assert_close(g.dist.invU.U, c[pre + "U"], tol, what=pre + "U")
+            assert_close(g.dist.invU.logdet_invU, c[pre + "logdet_invU"], tol, what=pre + "logdet")
+    assert torch.equal(g.assignment().cpu(), c["final_assignment"])
+    assert_close(g.KLqprior(), c["final_KLqprior"], 1e-8)
+
+
+def test_mixture_batched_golden(golden):
+    """Mixture with batch_shape (3,), 6 components, event (3,2): the generic (non-fused) E-step."""
+    from pyvbmp_amd.dists import Mixture, NormalInverseWishart
+    c = golden("gmm")["mixture_b3_k6_e32"]
+    niw = NormalInverseWishart(event_shape=(3, 2), batch_shape=(3, 6), device=DEV, dtype=torch.float64)
+    mix = Mixture(niw, event_shape=(6,))
+    niw.mu = c["init_mu"].to(DEV)
+    mix.pi.alpha = c["init_alpha"].to(DEV)
+    X = c["X"].to(DEV)
+    for it in (1, 2, 3):
+        mix.update(X, iters=1, lr=0.9)
+        pre = f"it{it}_"
+        for f in ("p", "NA", "logZ"):
+            assert_close(getattr(mix, f), c[pre + f], 1e-9, what=pre + f)
+        assert_close(mix.ELBO_last, c[pre + "ELBO"], 1e-9)
+        assert_close(mix.pi.alpha, c[pre + "alpha"], 1e-9)
+        assert_close(niw.mu, c[pre + "mu"], 1e-9)
+        assert_close(niw.invU.invU, c[pre + "invU"], 1e-9)
+        assert_close(niw.invU.U, c[pre + "U"], 1e-9)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("K,D,N", [(4, 16, 20011), (7, 3, 5000), (16, 32, 3001), (3, 40, 777)])
+def test_gmm_iteration_vs_oracle(K, D, N, dtype):
+    """One full VB iteration (fused E-step K3, moments K4, update K2) against the oracle."""
+    from oracle import mixture as omix
+    from oracle import niw as oniw
+    from pyvbmp_amd.models import GaussianMixtureModel
+    g = torch.Generator().manual_seed(K * 100 + D)
+    centers = 3.0 * torch.randn(K, D, generator=g, dtype=torch.float64)
+    X = (centers[torch.randint(K, (N,), generator=g)] + torch.randn(N, D, generator=g, dtype=torch.float64)).to(dtype)
+    m = GaussianMixtureModel(K, D, device=DEV, dtype=dtype)
+    m.dist.mu = centers.to(dtype).to(DEV) + 0.1
+    st = oniw.niw_new((D,), (K,), scale=1.0 / K ** (1.0 / D), mu_init=(centers.to(dtype) + 0.1).double())
+    alpha_0 = m.pi.alpha_0.cpu().double()
+    alpha = m.pi.alpha.cpu().double()
+    tol = TOL64 if dtype == torch.float64 else 2e-4
+    for it in range(2):
+        m.update(X.to(DEV), iters=1, lr=1.0)
+        st, alpha, out = omix.mixture_iteration(st, alpha_0, alpha, X.double(), 1.0, (K,), (), (D,))
+        assert_close(m.p, out["p"], tol, what="p")
+        assert_close(m.NA, out["NA"], tol, what="NA")
+        assert_close(m.logZ, out["logZ"], tol, what="logZ")
+        assert_close(m.dist.mu, st["mu"], tol, what="mu")
+        assert_close(m.dist.invU.invU, st["W"]["invU"], tol, what="invU")
+        assert_close(m.dist.invU.U, st["W"]["U"], tol * 10, what="U")
+        assert_close(m.pi.alpha, alpha, tol, what="alpha")
+
+
+def test_weighted_moments_linearity_large():
+    """Size-independent property at scale: moments are linear in the weights and additive over
+    sample chunks (N = 2e6 samples, K = 4, D = 16)."""
+    from pyvbmp_amd import ops
+    N, K, D = 2_000_000, 4, 16
+    g = torch.Generator(device=DEV).manual_seed(3)
+    X = torch.randn(N, 1, D, generator=g, dtype=torch.float64, device=DEV)
+    p = torch.rand(N, K, generator=g, dtype=torch.float64, device=DEV)
+    Nk, SEx, SExx = ops.weighted_moments(X, p, 1, (K,))
+    h = N // 2
+    N1, S1, Q1 = ops.weighted_moments(X[:h], p[:h], 1, (K,))
+    N2, S2, Q2 = ops.weighted_moments(X[h:], 2.0 * p[h:], 1, (K,))
+    assert_close(N1 + 0.5 * N2, Nk, 1e-11)
+    assert_close(S1 + 0.5 * S2, SEx, 1e-9)  # sums of zero-mean terms: compare against the scale of SExx
+    assert_close(Q1 + 0.5 * Q2, SExx, 1e-11)
+    ref = torch.einsum("nk,ni,nj->kij", p[:100000], X[:100000, 0], X[:100000, 0])
+    Q, = ops.weighted_moments(X[:100000], p[:100000], 1, (K,))[2:]
+    assert_close(Q, ref, 1e-11)
