@@ -102,8 +102,7 @@ class NormalInverseWishart():
         sample_shape = tuple(X.shape[:X.ndim - nd])
         mat_batch = self.batch_shape + self.event_shape[:-1]
         if p is None:
-            N, SEx, SExx = ops.weighted_moments(X, None, len(sample_shape), mat_batch)
-            N = N.reshape(()).expand(mat_batch)  # prod(sample_shape), as a tensor
+            N, SEx, SExx = ops.weighted_moments(X, None, len(sample_shape), mat_batch)  # N = prod(sample_shape)
         else:
             pv = p.reshape(tuple(p.shape) + (1,) * (self.event_dim - 1))
             N, SEx, SExx = ops.weighted_moments(X, pv, len(sample_shape), mat_batch)
