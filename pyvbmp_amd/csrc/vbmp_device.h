@@ -5,9 +5,9 @@
 // of G lanes; lane `lig` of the group keeps rows lig, lig+G, ... (R = Dp/G of them) entirely in
 // registers.  Global memory is always touched with linear, 16-byte-per-lane, full-cache-line
 // accesses of the tile's contiguous bytes; the (coalesced <-> row-per-lane) transposition goes
-// through a padded, per-wave LDS image.  Dense factor/inverse work then runs out of registers with
-// the pivot row broadcast inside the lane group (DPP row_newbcast for G=16, quad_perm for G=4,
-// v_readlane for G=64, nothing for G=1).
+// through a padded, per-wave LDS image.  Dense elimination then runs out of registers; the pivot
+// row reaches the other lanes of the group INSIDE the FMA (v_fmac_*_dpp row_newbcast for G=16,
+// quad_perm for G=4), via v_readlane for G=64, and is simply there for G=1.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -24,15 +24,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // ---------------------------------------------------------------- lane-group broadcast
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
-}
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov(double v) {
-  // the backend keeps a 64-bit row_newbcast as one DP-rate DPP move (v_mov_b64_dpp) on gfx950
-  return __builtin_amdgcn_update_dpp(0.0, v, CTRL, 0xF, 0xF, false);
-}
+// All DPP instructions are issued from inline asm that begins with `s_nop 1`: a DPP operand read
+// needs 2 wait states after the VALU write of that register, and hipcc pads nothing around asm.
 __device__ __forceinline__ float readlane_any(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
@@ -44,20 +37,176 @@ __device__ __forceinline__ double readlane_any(double v, int lane) {
   return u.d;
 }
 
+#define VBMP_DPP16 "row_newbcast:%c[src] row_mask:0xf bank_mask:0xf"
+#define VBMP_DPP4 "quad_perm:[%c[src],%c[src],%c[src],%c[src]] row_mask:0xf bank_mask:0xf"
+
 // value of `v` held by lane SRC of this lane's G-lane group
-template <int G, int SRC, typename T>
-__device__ __forceinline__ T bcast(T v) {
+template <int G, int SRC>
+__device__ __forceinline__ double bcast(double v) {
   static_assert(SRC >= 0 && SRC < G, "source lane outside the group");
   if constexpr (G == 1) {
     return v;
-  } else if constexpr (G == 4) {
-    return dpp_mov<(SRC) | (SRC << 2) | (SRC << 4) | (SRC << 6)>(v);  // quad_perm:[SRC,SRC,SRC,SRC]
   } else if constexpr (G == 16) {
-    return dpp_mov<0x150 + SRC>(v);  // row_newbcast:SRC
+    double r;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %[r], %[v] " VBMP_DPP16 : [r] "=&v"(r) : [v] "v"(v), [src] "n"(SRC));
+    return r;
+  } else if constexpr (G == 4) {
+    // no 64-bit quad_perm: move the two halves
+    union { double d; int i[2]; } a, b;
+    a.d = v;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %[r0], %[v0] " VBMP_DPP4 "\n\tv_mov_b32_dpp %[r1], %[v1] " VBMP_DPP4
+                 : [r0] "=&v"(b.i[0]), [r1] "=&v"(b.i[1])
+                 : [v0] "v"(a.i[0]), [v1] "v"(a.i[1]), [src] "n"(SRC));
+    return b.d;
   } else if constexpr (G == 64) {
     return readlane_any(v, SRC);
   } else {
     return __shfl(v, SRC, G);
+  }
+}
+template <int G, int SRC>
+__device__ __forceinline__ float bcast(float v) {
+  static_assert(SRC >= 0 && SRC < G, "source lane outside the group");
+  if constexpr (G == 1) {
+    return v;
+  } else if constexpr (G == 16) {
+    float r;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %[r], %[v] " VBMP_DPP16 : [r] "=&v"(r) : [v] "v"(v), [src] "n"(SRC));
+    return r;
+  } else if constexpr (G == 4) {
+    float r;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %[r], %[v] " VBMP_DPP4 : [r] "=&v"(r) : [v] "v"(v), [src] "n"(SRC));
+    return r;
+  } else if constexpr (G == 64) {
+    return readlane_any(v, SRC);
+  } else {
+    return __shfl(v, SRC, G);
+  }
+}
+
+__device__ __forceinline__ double xfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float xfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// acc += f * (value of `v` on lane SRC of the group): one instruction for G in {4,16}
+template <int G, int SRC>
+__device__ __forceinline__ void fmac_bcast(double& acc, double v, double f) {
+  if constexpr (G == 16) {
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %[a], %[v], %[f] " VBMP_DPP16 : [a] "+v"(acc) : [v] "v"(v), [f] "v"(f), [src] "n"(SRC));
+  } else {
+    acc = xfma(bcast<G, SRC>(v), f, acc);
+  }
+}
+template <int G, int SRC>
+__device__ __forceinline__ void fmac_bcast(float& acc, float v, float f) {
+  if constexpr (G == 16) {
+    asm volatile("s_nop 1\n\tv_fmac_f32_dpp %[a], %[v], %[f] " VBMP_DPP16 : [a] "+v"(acc) : [v] "v"(v), [f] "v"(f), [src] "n"(SRC));
+  } else if constexpr (G == 4) {
+    asm volatile("s_nop 1\n\tv_fmac_f32_dpp %[a], %[v], %[f] " VBMP_DPP4 : [a] "+v"(acc) : [v] "v"(v), [f] "v"(f), [src] "n"(SRC));
+  } else {
+    acc = xfma(bcast<G, SRC>(v), f, acc);
+  }
+}
+
+// acc[j] += f * (piv[j] on lane SRC), j = 0..3: one s_nop + four DPP FMAs
+template <int G, int SRC>
+__device__ __forceinline__ void fmac_bcast4(double* acc, const double* piv, double f) {
+  if constexpr (G == 16) {
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f64_dpp %[a0], %[p0], %[f] " VBMP_DPP16 "\n\t"
+                 "v_fmac_f64_dpp %[a1], %[p1], %[f] " VBMP_DPP16 "\n\t"
+                 "v_fmac_f64_dpp %[a2], %[p2], %[f] " VBMP_DPP16 "\n\t"
+                 "v_fmac_f64_dpp %[a3], %[p3], %[f] " VBMP_DPP16
+                 : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3])
+                 : [p0] "v"(piv[0]), [p1] "v"(piv[1]), [p2] "v"(piv[2]), [p3] "v"(piv[3]), [f] "v"(f), [src] "n"(SRC));
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = xfma(bcast<G, SRC>(piv[j]), f, acc[j]);
+  }
+}
+template <int G, int SRC>
+__device__ __forceinline__ void fmac_bcast4(float* acc, const float* piv, float f) {
+  if constexpr (G == 16) {
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f32_dpp %[a0], %[p0], %[f] " VBMP_DPP16 "\n\t"
+                 "v_fmac_f32_dpp %[a1], %[p1], %[f] " VBMP_DPP16 "\n\t"
+                 "v_fmac_f32_dpp %[a2], %[p2], %[f] " VBMP_DPP16 "\n\t"
+                 "v_fmac_f32_dpp %[a3], %[p3], %[f] " VBMP_DPP16
+                 : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3])
+                 : [p0] "v"(piv[0]), [p1] "v"(piv[1]), [p2] "v"(piv[2]), [p3] "v"(piv[3]), [f] "v"(f), [src] "n"(SRC));
+  } else if constexpr (G == 4) {
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f32_dpp %[a0], %[p0], %[f] " VBMP_DPP4 "\n\t"
+                 "v_fmac_f32_dpp %[a1], %[p1], %[f] " VBMP_DPP4 "\n\t"
+                 "v_fmac_f32_dpp %[a2], %[p2], %[f] " VBMP_DPP4 "\n\t"
+                 "v_fmac_f32_dpp %[a3], %[p3], %[f] " VBMP_DPP4
+                 : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3])
+                 : [p0] "v"(piv[0]), [p1] "v"(piv[1]), [p2] "v"(piv[2]), [p3] "v"(piv[3]), [f] "v"(f), [src] "n"(SRC));
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = xfma(bcast<G, SRC>(piv[j]), f, acc[j]);
+  }
+}
+
+// acc[j] += f * (acc[j] on lane SRC), j = 0..3  (the row is its own pivot slot: the DPP source and the
+// destination are the same register, so it must be ONE asm operand or the compiler copies it first)
+template <int G, int SRC>
+__device__ __forceinline__ void fmac_self4(double* acc, double f) {
+  if constexpr (G == 16) {
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f64_dpp %[a0], %[a0], %[f] " VBMP_DPP16 "\n\t"
+                 "v_fmac_f64_dpp %[a1], %[a1], %[f] " VBMP_DPP16 "\n\t"
+                 "v_fmac_f64_dpp %[a2], %[a2], %[f] " VBMP_DPP16 "\n\t"
+                 "v_fmac_f64_dpp %[a3], %[a3], %[f] " VBMP_DPP16
+                 : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3])
+                 : [f] "v"(f), [src] "n"(SRC));
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = xfma(bcast<G, SRC>(acc[j]), f, acc[j]);
+  }
+}
+template <int G, int SRC>
+__device__ __forceinline__ void fmac_self4(float* acc, float f) {
+  if constexpr (G == 16) {
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f32_dpp %[a0], %[a0], %[f] " VBMP_DPP16 "\n\t"
+                 "v_fmac_f32_dpp %[a1], %[a1], %[f] " VBMP_DPP16 "\n\t"
+                 "v_fmac_f32_dpp %[a2], %[a2], %[f] " VBMP_DPP16 "\n\t"
+                 "v_fmac_f32_dpp %[a3], %[a3], %[f] " VBMP_DPP16
+                 : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3])
+                 : [f] "v"(f), [src] "n"(SRC));
+  } else if constexpr (G == 4) {
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f32_dpp %[a0], %[a0], %[f] " VBMP_DPP4 "\n\t"
+                 "v_fmac_f32_dpp %[a1], %[a1], %[f] " VBMP_DPP4 "\n\t"
+                 "v_fmac_f32_dpp %[a2], %[a2], %[f] " VBMP_DPP4 "\n\t"
+                 "v_fmac_f32_dpp %[a3], %[a3], %[f] " VBMP_DPP4
+                 : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3])
+                 : [f] "v"(f), [src] "n"(SRC));
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = xfma(bcast<G, SRC>(acc[j]), f, acc[j]);
+  }
+}
+template <int G, int SRC, int Dp, typename T>
+__device__ __forceinline__ void fmac_self_row(T (&acc)[Dp], T f) {
+  if constexpr (Dp % 4 == 0) {
+#pragma unroll
+    for (int c = 0; c < Dp / 4; ++c) fmac_self4<G, SRC>(&acc[4 * c], f);
+  } else {
+#pragma unroll
+    for (int j = 0; j < Dp; ++j) acc[j] = xfma(bcast<G, SRC>(acc[j]), f, acc[j]);
+  }
+}
+
+// acc[0..Dp) += f * (piv[0..Dp) on lane SRC)
+template <int G, int SRC, int Dp, typename T>
+__device__ __forceinline__ void fmac_bcast_row(T (&acc)[Dp], const T (&piv)[Dp], T f) {
+  if constexpr (Dp % 4 == 0) {
+#pragma unroll
+    for (int c = 0; c < Dp / 4; ++c) fmac_bcast4<G, SRC>(&acc[4 * c], &piv[4 * c], f);
+  } else {
+#pragma unroll
+    for (int j = 0; j < Dp; ++j) acc[j] = xfma(bcast<G, SRC>(piv[j]), f, acc[j]);
   }
 }
 
@@ -77,29 +226,25 @@ __device__ __forceinline__ float rcp_nr(float d) {
   float e = __builtin_fmaf(-d, r, 1.0f);
   return __builtin_fmaf(r, e, r);
 }
-__device__ __forceinline__ double xfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
-__device__ __forceinline__ float xfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double frexp_m(double d) { return __builtin_amdgcn_frexp_mant(d); }
+__device__ __forceinline__ float frexp_m(float d) { return __builtin_amdgcn_frexp_mantf(d); }
+__device__ __forceinline__ int frexp_e(double d) { return __builtin_amdgcn_frexp_exp(d); }
+__device__ __forceinline__ int frexp_e(float d) { return __builtin_amdgcn_frexp_expf(d); }
 
-// running log|det| kept as (mantissa product, exponent sum, sign): one log per matrix at the end
+// running det kept as (signed mantissa product, exponent sum): one log per matrix at the end.
+// log of a negative product is NaN and of zero is -inf, which is exactly Tensor.logdet().
 template <typename T>
 struct LogDet {
   T mant = T(1);
   int expo = 0;
-  bool neg = false;
-  bool bad = false;  // a zero / NaN pivot
+  bool allpos = true;  // every pivot > 0  <=>  the matrix is positive definite
   __device__ __forceinline__ void mul(T d) {
-    bad |= !(d != T(0)) || !(d == d);
-    neg ^= (d < T(0));
-    int e;
-    T m = frexp(d < T(0) ? -d : d, &e);
-    mant *= m;  // m in [0.5,1): at most 64 factors, cannot underflow
-    expo += e;
+    allpos = allpos && (d > T(0));
+    mant *= frexp_m(d);  // |m| in [0.5,1): at most 64 factors, cannot underflow
+    expo += frexp_e(d);
   }
-  // log(det) with the reference's Tensor.logdet() conventions: NaN when det < 0, -inf when det == 0
   __device__ __forceinline__ T value() const {
-    T v = log(mant) + T(expo) * T(0.693147180559945309417232121458);
-    if (neg) v = __builtin_nan("");
-    return v;
+    return log(mant) + T(expo) * T(0.693147180559945309417232121458);
   }
 };
 
@@ -116,93 +261,137 @@ struct Tile {
   using vec_t = T __attribute__((ext_vector_type(V)));
 };
 
-// wave-level ordering of LDS traffic (one wave owns its LDS image; no block barrier needed)
+// wave-level ordering of LDS traffic (one wave owns its LDS image; no block barrier needed).
+// The fences name the LDS address space only, so they cost an lgkmcnt wait and do NOT drain the
+// global loads/stores that are still in flight.
 __device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
 // global (linear, coalesced) -> per-wave LDS image [m][row][col] with padded strides.
 // g points at the first matrix of the tile; matrices are `gstride` elements apart; `nm` valid.
-template <typename T, int Dp, int G>
-__device__ __forceinline__ void tile_g2lds(const T* __restrict__ g, int64_t gstride, int nm, int D, T* __restrict__ lds,
-                                           int lane) {
+// FULL: D == Dp, the tile is contiguous and 16-byte aligned (checked on the host) -> all index
+// arithmetic folds to shifts and the 16-byte path is unconditional.
+template <typename T, int Dp, int G, bool FULL>
+__device__ __forceinline__ void tile_g2lds(const T* __restrict__ g, int64_t gstride, int nm, int Drt,
+                                           T* __restrict__ lds, int lane) {
   using TL = Tile<T, Dp, G>;
+  const int D = FULL ? Dp : Drt;
   const int DD = D * D;
-  const bool contiguous = (gstride == DD);
-  const bool vec_ok = contiguous && (D % TL::V == 0) && ((reinterpret_cast<uintptr_t>(g) & 15) == 0);
-  if (vec_ok) {
-    const int nchunk = nm * DD / TL::V;  // chunks never straddle a row because D % V == 0
-    const int cpr = D / TL::V;           // chunks per row
+  if constexpr (FULL && (Dp % TL::V == 0)) {
+    constexpr int cpr = Dp / TL::V;                                // chunks per row
+    constexpr int NIT = (TL::MPW * Dp * Dp / TL::V + 63) / 64;     // full-tile trip count
+    const int nchunk = nm * (Dp * Dp / TL::V);
     const typename TL::vec_t* gv = reinterpret_cast<const typename TL::vec_t*>(g);
-    for (int c = lane; c < nchunk; c += 64) {
-      typename TL::vec_t v = gv[c];
-      int row_all = c / cpr;             // row index across the tile
-      int cc = c - row_all * cpr;
-      int m = row_all / D;
-      int row = row_all - m * D;
-      *reinterpret_cast<typename TL::vec_t*>(&lds[m * TL::MS + row * TL::RS + cc * TL::V]) = v;
+    // branch-free: a partial last tile re-reads its final chunk and fills LDS slots nobody consumes
+    typename TL::vec_t v[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = gv[c < nchunk ? c : nchunk - 1];
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int c = lane + 64 * i;
+      const int row_all = c / cpr, cc = c % cpr;
+      const int m = row_all / Dp, row = row_all % Dp;
+      if (c < TL::MPW * Dp * Dp / TL::V)
+        *reinterpret_cast<typename TL::vec_t*>(&lds[m * TL::MS + row * TL::RS + cc * TL::V]) = v[i];
     }
   } else {
-    const int n = nm * DD;
-    for (int e = lane; e < n; e += 64) {
-      int m = e / DD;
-      int rem = e - m * DD;
-      int row = rem / D;
-      int col = rem - row * D;
-      lds[m * TL::MS + row * TL::RS + col] = g[(int64_t)m * gstride + rem];
+    const bool vec_ok = (gstride == DD) && (D % TL::V == 0) && ((reinterpret_cast<uintptr_t>(g) & 15) == 0);
+    if (vec_ok) {
+      const int nchunk = nm * DD / TL::V;  // chunks never straddle a row because D % V == 0
+      const int cpr = D / TL::V;
+      const typename TL::vec_t* gv = reinterpret_cast<const typename TL::vec_t*>(g);
+      for (int c = lane; c < nchunk; c += 64) {
+        typename TL::vec_t v = gv[c];
+        int row_all = c / cpr;
+        int cc = c - row_all * cpr;
+        int m = row_all / D;
+        int row = row_all - m * D;
+        *reinterpret_cast<typename TL::vec_t*>(&lds[m * TL::MS + row * TL::RS + cc * TL::V]) = v;
+      }
+    } else {
+      const int n = nm * DD;
+      for (int e = lane; e < n; e += 64) {
+        int m = e / DD;
+        int rem = e - m * DD;
+        int row = rem / D;
+        int col = rem - row * D;
+        lds[m * TL::MS + row * TL::RS + col] = g[(int64_t)m * gstride + rem];
+      }
     }
   }
 }
 
 // per-wave LDS image -> global (linear, coalesced)
-template <typename T, int Dp, int G>
-__device__ __forceinline__ void tile_lds2g(T* __restrict__ g, int nm, int D, const T* __restrict__ lds, int lane) {
+template <typename T, int Dp, int G, bool FULL>
+__device__ __forceinline__ void tile_lds2g(T* __restrict__ g, int nm, int Drt, const T* __restrict__ lds, int lane) {
   using TL = Tile<T, Dp, G>;
+  const int D = FULL ? Dp : Drt;
   const int DD = D * D;
-  const bool vec_ok = (D % TL::V == 0) && ((reinterpret_cast<uintptr_t>(g) & 15) == 0);
-  if (vec_ok) {
-    const int nchunk = nm * DD / TL::V;
-    const int cpr = D / TL::V;
+  if constexpr (FULL && (Dp % TL::V == 0)) {
+    constexpr int cpr = Dp / TL::V;
+    constexpr int NIT = (TL::MPW * Dp * Dp / TL::V + 63) / 64;
+    const int nchunk = nm * (Dp * Dp / TL::V);
     typename TL::vec_t* gv = reinterpret_cast<typename TL::vec_t*>(g);
-    for (int c = lane; c < nchunk; c += 64) {
-      int row_all = c / cpr;
-      int cc = c - row_all * cpr;
-      int m = row_all / D;
-      int row = row_all - m * D;
-      gv[c] = *reinterpret_cast<const typename TL::vec_t*>(&lds[m * TL::MS + row * TL::RS + cc * TL::V]);
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int c = lane + 64 * i;
+      const int row_all = c / cpr, cc = c % cpr;
+      const int m = row_all / Dp, row = row_all % Dp;
+      if (c < nchunk)
+        gv[c] = *reinterpret_cast<const typename TL::vec_t*>(&lds[m * TL::MS + row * TL::RS + cc * TL::V]);
     }
   } else {
-    const int n = nm * DD;
-    for (int e = lane; e < n; e += 64) {
-      int m = e / DD;
-      int rem = e - m * DD;
-      int row = rem / D;
-      int col = rem - row * D;
-      g[e] = lds[m * TL::MS + row * TL::RS + col];
+    const bool vec_ok = (D % TL::V == 0) && ((reinterpret_cast<uintptr_t>(g) & 15) == 0);
+    if (vec_ok) {
+      const int nchunk = nm * DD / TL::V;
+      const int cpr = D / TL::V;
+      typename TL::vec_t* gv = reinterpret_cast<typename TL::vec_t*>(g);
+      for (int c = lane; c < nchunk; c += 64) {
+        int row_all = c / cpr;
+        int cc = c - row_all * cpr;
+        int m = row_all / D;
+        int row = row_all - m * D;
+        gv[c] = *reinterpret_cast<const typename TL::vec_t*>(&lds[m * TL::MS + row * TL::RS + cc * TL::V]);
+      }
+    } else {
+      const int n = nm * DD;
+      for (int e = lane; e < n; e += 64) {
+        int m = e / DD;
+        int rem = e - m * DD;
+        int row = rem / D;
+        int col = rem - row * D;
+        g[e] = lds[m * TL::MS + row * TL::RS + col];
+      }
     }
   }
 }
 
 // LDS image -> this lane's rows.  Rows/cols >= D are padded with the identity.
-template <typename T, int Dp, int G, int R>
-__device__ __forceinline__ void tile_lds2rows(const T* __restrict__ lds, int mloc, int lig, int D, T (&a)[R][Dp]) {
+template <typename T, int Dp, int G, int R, bool FULL>
+__device__ __forceinline__ void tile_lds2rows(const T* __restrict__ lds, int mloc, int lig, int Drt, T (&a)[R][Dp]) {
   using TL = Tile<T, Dp, G>;
+  const int D = FULL ? Dp : Drt;
 #pragma unroll
-  for (int q = 0; q < TL::R; ++q) {
+  for (int q = 0; q < R; ++q) {
     const int row = lig + G * q;
     const T* src = &lds[mloc * TL::MS + row * TL::RS];
-    if (D == Dp) {
+    if (FULL) {
+      if constexpr (Dp % TL::V == 0) {
 #pragma unroll
-      for (int c = 0; c < Dp / TL::V; ++c) {
-        typename TL::vec_t v = *reinterpret_cast<const typename TL::vec_t*>(&src[c * TL::V]);
+        for (int c = 0; c < Dp / TL::V; ++c) {
+          typename TL::vec_t v = *reinterpret_cast<const typename TL::vec_t*>(&src[c * TL::V]);
 #pragma unroll
-        for (int u = 0; u < TL::V; ++u) a[q][c * TL::V + u] = v[u];
-      }
-      if constexpr (Dp % TL::V != 0) {
+          for (int u = 0; u < TL::V; ++u) a[q][c * TL::V + u] = v[u];
+        }
+      } else {
 #pragma unroll
-        for (int j = (Dp / TL::V) * TL::V; j < Dp; ++j) a[q][j] = src[j];
+        for (int j = 0; j < Dp; ++j) a[q][j] = src[j];
       }
     } else {
 #pragma unroll
@@ -215,24 +404,26 @@ __device__ __forceinline__ void tile_lds2rows(const T* __restrict__ lds, int mlo
 }
 
 // this lane's rows -> LDS image (only the D x D part)
-template <typename T, int Dp, int G, int R>
-__device__ __forceinline__ void tile_rows2lds(T* __restrict__ lds, int mloc, int lig, int D, const T (&a)[R][Dp]) {
+template <typename T, int Dp, int G, int R, bool FULL>
+__device__ __forceinline__ void tile_rows2lds(T* __restrict__ lds, int mloc, int lig, int Drt, const T (&a)[R][Dp]) {
   using TL = Tile<T, Dp, G>;
+  const int D = FULL ? Dp : Drt;
 #pragma unroll
-  for (int q = 0; q < TL::R; ++q) {
+  for (int q = 0; q < R; ++q) {
     const int row = lig + G * q;
     T* dst = &lds[mloc * TL::MS + row * TL::RS];
-    if (D == Dp) {
+    if (FULL) {
+      if constexpr (Dp % TL::V == 0) {
 #pragma unroll
-      for (int c = 0; c < Dp / TL::V; ++c) {
-        typename TL::vec_t v;
+        for (int c = 0; c < Dp / TL::V; ++c) {
+          typename TL::vec_t v;
 #pragma unroll
-        for (int u = 0; u < TL::V; ++u) v[u] = a[q][c * TL::V + u];
-        *reinterpret_cast<typename TL::vec_t*>(&dst[c * TL::V]) = v;
-      }
-      if constexpr (Dp % TL::V != 0) {
+          for (int u = 0; u < TL::V; ++u) v[u] = a[q][c * TL::V + u];
+          *reinterpret_cast<typename TL::vec_t*>(&dst[c * TL::V]) = v;
+        }
+      } else {
 #pragma unroll
-        for (int j = (Dp / TL::V) * TL::V; j < Dp; ++j) dst[j] = a[q][j];
+        for (int j = 0; j < Dp; ++j) dst[j] = a[q][j];
       }
     } else if (row < D) {
 #pragma unroll
@@ -244,11 +435,17 @@ __device__ __forceinline__ void tile_rows2lds(T* __restrict__ lds, int mloc, int
 
 // ---------------------------------------------------------------- in-register Gauss-Jordan
 // In-place inverse of the (symmetric, normally SPD) matrix whose rows lig+G*q live in a[q][*].
-// No pivoting (SPD => pivots are the positive Schur complements).  `ld` accumulates log|det| and
-// the determinant's sign so that the caller can mirror Tensor.logdet() (NaN for det < 0).
+// No pivoting (SPD => the pivots are the positive Schur complements).  The pivot row is never
+// scaled in place: row r keeps the factor 1/pivot_r aside (`sc`) and every later update is linear
+// in the row, so the scale is applied once at the end -- this removes Dp multiplies per step and
+// lets every other row consume the UNSCALED pivot row straight out of the owner's registers
+// through the DPP operand of the FMA.
 template <typename T, int Dp, int G, int R>
 __device__ __forceinline__ void gj_inverse(T (&a)[R][Dp], int lig, LogDet<T>& ld) {
   static_assert(R * G == Dp, "rows per lane x lanes per matrix must cover the padded dim");
+  T sc[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q) sc[q] = T(1);
   static_for<0, Dp>([&](auto K) {
     constexpr int k = decltype(K)::value;
     constexpr int src = k % G;   // lane (in group) that owns the pivot row
@@ -257,22 +454,23 @@ __device__ __forceinline__ void gj_inverse(T (&a)[R][Dp], int lig, LogDet<T>& ld
     const T d = bcast<G, src>(a[slot][k]);
     ld.mul(d);
     const T p = rcp_nr(d);
-    const T s = owner ? p : T(1);
-    // the owner scales its pivot row (x1 elsewhere: exact)
-#pragma unroll
-    for (int j = 0; j < Dp; ++j)
-      if (j != k) a[slot][j] *= s;
-#pragma unroll
-    for (int q = 0; q < R; ++q) {
+    sc[slot] = owner ? p : sc[slot];
+    // rows in the pivot slot go last: their destination registers are this step's DPP sources
+    static_for<0, R>([&](auto Q) {
+      constexpr int q = (decltype(Q)::value + slot + 1) % R;
       const bool is_piv = owner && (q == slot);
-      const T f = a[q][k];
-      const T nf = is_piv ? T(0) : -f;
-#pragma unroll
-      for (int j = 0; j < Dp; ++j)
-        if (j != k) a[q][j] = xfma(nf, bcast<G, src>(a[slot][j]), a[q][j]);
-      a[q][k] = is_piv ? p : nf * p;
-    }
+      const T nf = is_piv ? T(0) : -(a[q][k] * p);
+      if constexpr (q == slot)
+        fmac_self_row<G, src, Dp, T>(a[q], nf);
+      else
+        fmac_bcast_row<G, src, Dp, T>(a[q], a[slot], nf);
+      a[q][k] = is_piv ? T(1) : nf;
+    });
   });
+#pragma unroll
+  for (int q = 0; q < R; ++q)
+#pragma unroll
+    for (int j = 0; j < Dp; ++j) a[q][j] *= sc[q];
 }
 
 }  // namespace vbmp
