@@ -124,16 +124,29 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    # HIP events recorded by the launch hooks right around the kernel enqueue, on torch's current
+    # stream (= the stream handed to the C-ABI), so each pair brackets exactly one kernel launch.
+    starts, stops = [], []
+
+    def before(name):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        starts.append(ev)
+
+    def after(name):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        stops.append(ev)
+
     barrier()
+    _lib.launch_hooks = (before, after)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        starts[i].record()  # torch's current stream == the stream the kernel is enqueued on
         step()
-        stops[i].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    _lib.launch_hooks = None
+    assert len(starts) == args.steps == len(stops), "one kernel launch per step expected"
     kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, stops)) / args.steps
     if dist is not None:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=device)

@@ -121,6 +121,23 @@ def ptr(t):
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
 
+# Optional (before, after) callables run immediately around every kernel enqueue.  bench.py uses them to
+# record HIP events right at the launch, so that the event pair brackets the kernel and not the
+# Python-side marshalling in front of it.
+launch_hooks = None
+
+
+def call(fn, name, *args):
+    """Enqueue one C-ABI kernel call (with the optional timing hooks) and raise on a non-zero code."""
+    hooks = launch_hooks
+    if hooks is not None:
+        hooks[0](name)
+    rc = fn(*args)
+    if hooks is not None:
+        hooks[1](name)
+    check(rc, name)
+
+
 def check(rc, name):
     if rc != 0:
         raise VbmpHipError(f"{name} failed with code {rc} "

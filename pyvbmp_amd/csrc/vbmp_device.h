@@ -187,9 +187,43 @@ __device__ __forceinline__ void fmac_self4(float* acc, float f) {
     for (int j = 0; j < 4; ++j) acc[j] = xfma(bcast<G, SRC>(acc[j]), f, acc[j]);
   }
 }
+// eight at a time (18 asm operands): halves the number of hazard pads per row
+template <int G, int SRC>
+__device__ __forceinline__ void fmac_self8(double* acc, double f) {
+  asm volatile("s_nop 1\n\t"
+               "v_fmac_f64_dpp %[a0], %[a0], %[f] " VBMP_DPP16 "\n\t"
+               "v_fmac_f64_dpp %[a1], %[a1], %[f] " VBMP_DPP16 "\n\t"
+               "v_fmac_f64_dpp %[a2], %[a2], %[f] " VBMP_DPP16 "\n\t"
+               "v_fmac_f64_dpp %[a3], %[a3], %[f] " VBMP_DPP16 "\n\t"
+               "v_fmac_f64_dpp %[a4], %[a4], %[f] " VBMP_DPP16 "\n\t"
+               "v_fmac_f64_dpp %[a5], %[a5], %[f] " VBMP_DPP16 "\n\t"
+               "v_fmac_f64_dpp %[a6], %[a6], %[f] " VBMP_DPP16 "\n\t"
+               "v_fmac_f64_dpp %[a7], %[a7], %[f] " VBMP_DPP16
+               : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [a4] "+v"(acc[4]),
+                 [a5] "+v"(acc[5]), [a6] "+v"(acc[6]), [a7] "+v"(acc[7])
+               : [f] "v"(f), [src] "n"(SRC));
+}
+template <int G, int SRC>
+__device__ __forceinline__ void fmac_self8(float* acc, float f) {
+  asm volatile("s_nop 1\n\t"
+               "v_fmac_f32_dpp %[a0], %[a0], %[f] " VBMP_DPP16 "\n\t"
+               "v_fmac_f32_dpp %[a1], %[a1], %[f] " VBMP_DPP16 "\n\t"
+               "v_fmac_f32_dpp %[a2], %[a2], %[f] " VBMP_DPP16 "\n\t"
+               "v_fmac_f32_dpp %[a3], %[a3], %[f] " VBMP_DPP16 "\n\t"
+               "v_fmac_f32_dpp %[a4], %[a4], %[f] " VBMP_DPP16 "\n\t"
+               "v_fmac_f32_dpp %[a5], %[a5], %[f] " VBMP_DPP16 "\n\t"
+               "v_fmac_f32_dpp %[a6], %[a6], %[f] " VBMP_DPP16 "\n\t"
+               "v_fmac_f32_dpp %[a7], %[a7], %[f] " VBMP_DPP16
+               : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [a4] "+v"(acc[4]),
+                 [a5] "+v"(acc[5]), [a6] "+v"(acc[6]), [a7] "+v"(acc[7])
+               : [f] "v"(f), [src] "n"(SRC));
+}
 template <int G, int SRC, int Dp, typename T>
 __device__ __forceinline__ void fmac_self_row(T (&acc)[Dp], T f) {
-  if constexpr (Dp % 4 == 0) {
+  if constexpr (G == 16 && Dp % 8 == 0) {
+#pragma unroll
+    for (int c = 0; c < Dp / 8; ++c) fmac_self8<G, SRC>(&acc[8 * c], f);
+  } else if constexpr (Dp % 4 == 0) {
 #pragma unroll
     for (int c = 0; c < Dp / 4; ++c) fmac_self4<G, SRC>(&acc[4 * c], f);
   } else {
@@ -287,10 +321,15 @@ __device__ __forceinline__ void tile_g2lds(const T* __restrict__ g, int64_t gstr
     const typename TL::vec_t* gv = reinterpret_cast<const typename TL::vec_t*>(g);
     // branch-free: a partial last tile re-reads its final chunk and fills LDS slots nobody consumes
     typename TL::vec_t v[NIT];
+    if (nm == TL::MPW) {  // wave-uniform: constant offsets from one base address
 #pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int c = lane + 64 * i;
-      v[i] = gv[c < nchunk ? c : nchunk - 1];
+      for (int i = 0; i < NIT; ++i) v[i] = gv[lane + 64 * i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = gv[c < nchunk ? c : nchunk - 1];
+      }
     }
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
@@ -338,13 +377,23 @@ __device__ __forceinline__ void tile_lds2g(T* __restrict__ g, int nm, int Drt, c
     constexpr int NIT = (TL::MPW * Dp * Dp / TL::V + 63) / 64;
     const int nchunk = nm * (Dp * Dp / TL::V);
     typename TL::vec_t* gv = reinterpret_cast<typename TL::vec_t*>(g);
+    typename TL::vec_t v[NIT];
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
       const int c = lane + 64 * i;
       const int row_all = c / cpr, cc = c % cpr;
       const int m = row_all / Dp, row = row_all % Dp;
-      if (c < nchunk)
-        gv[c] = *reinterpret_cast<const typename TL::vec_t*>(&lds[m * TL::MS + row * TL::RS + cc * TL::V]);
+      if (c < TL::MPW * Dp * Dp / TL::V)
+        v[i] = *reinterpret_cast<const typename TL::vec_t*>(&lds[m * TL::MS + row * TL::RS + cc * TL::V]);
+    }
+    if (nm == TL::MPW) {  // wave-uniform: unpredicated stores, constant offsets
+#pragma unroll
+      for (int i = 0; i < NIT; ++i)
+        if (lane + 64 * i < TL::MPW * Dp * Dp / TL::V) gv[lane + 64 * i] = v[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NIT; ++i)
+        if (lane + 64 * i < nchunk) gv[lane + 64 * i] = v[i];
     }
   } else {
     const bool vec_ok = (D % TL::V == 0) && ((reinterpret_cast<uintptr_t>(g) & 15) == 0);

@@ -48,8 +48,7 @@ def spd_inv_logdet(A, want_logdet=True, nonspd=None):
     logdet = torch.empty(bshape, dtype=A.dtype, device=dev) if want_logdet else None
     if B > 0:
         fn = getattr(lib, "vbmp_spd_inv_logdet_" + L.suffix(A.dtype))
-        L.check(fn(L.ptr(Ac), D * D, L.ptr(Ainv), L.ptr(logdet), B, D, L.ptr(nonspd), L.stream_ptr(dev)),
-                "vbmp_spd_inv_logdet")
+        L.call(fn, "vbmp_spd_inv_logdet", L.ptr(Ac), D * D, L.ptr(Ainv), L.ptr(logdet), B, D, L.ptr(nonspd), L.stream_ptr(dev))
     return Ainv, logdet
 
 
@@ -84,9 +83,9 @@ def wishart_ss_update(SExx, N, invU0, nu0, invU_old, nu_old, lr, nonspd=None):
         suf = L.suffix(dt)
         fn = getattr(lib, "vbmp_wishart_ss_update_" + suf)
         cT = L.DTYPES[suf][1]
-        L.check(fn(L.ptr(SExx_c), sS, L.ptr(N_c), sN, L.ptr(i0), si0, L.ptr(n0), sn0, L.ptr(io), sio, L.ptr(no), sno,
+        L.call(fn, "vbmp_wishart_ss_update", L.ptr(SExx_c), sS, L.ptr(N_c), sN, L.ptr(i0), si0, L.ptr(n0), sn0, L.ptr(io), sio, L.ptr(no), sno,
                    cT(float(lr)), L.ptr(invU), L.ptr(nu), L.ptr(U), L.ptr(logdet), B, D, L.ptr(nonspd),
-                   L.stream_ptr(dev)), "vbmp_wishart_ss_update")
+                   L.stream_ptr(dev))
     return invU, nu, U, logdet
 
 
@@ -129,10 +128,10 @@ def niw_ss_update(SExx, SEx, N, lam0, mu0, invU0, nu0, lam_old, mu_old, invU_old
         suf = L.suffix(dt)
         fn = getattr(lib, "vbmp_niw_ss_update_" + suf)
         cT = L.DTYPES[suf][1]
-        L.check(fn(L.ptr(SExx_c), sS, L.ptr(SEx_c), sx, L.ptr(N_c), sN, L.ptr(l0), sl0, L.ptr(m0), sm0, L.ptr(i0), si0,
+        L.call(fn, "vbmp_niw_ss_update", L.ptr(SExx_c), sS, L.ptr(SEx_c), sx, L.ptr(N_c), sN, L.ptr(l0), sl0, L.ptr(m0), sm0, L.ptr(i0), si0,
                    L.ptr(n0), sn0, L.ptr(lo), slo, L.ptr(mo), smo, L.ptr(io), sio, L.ptr(no), sno, cT(float(lr)),
                    L.ptr(lam), L.ptr(mu), L.ptr(invU), L.ptr(nu), L.ptr(U), L.ptr(logdet), B, D,
-                   1 if fixed_precision else 0, L.ptr(nonspd), L.stream_ptr(dev)), "vbmp_niw_ss_update")
+                   1 if fixed_precision else 0, L.ptr(nonspd), L.stream_ptr(dev))
     return lam, mu, invU, nu, U, logdet
 
 
@@ -178,8 +177,7 @@ def quadform_loglike(X, P, b, c):
     out = torch.empty((S, Bo, Bi), dtype=dt, device=dev)
     if out.numel() > 0:
         fn = getattr(lib, "vbmp_quadform_loglike_" + L.suffix(dt))
-        L.check(fn(L.ptr(X2), S, Bo, Bi, D, L.ptr(Pc), L.ptr(bc), L.ptr(cc), L.ptr(out), L.stream_ptr(dev)),
-                "vbmp_quadform_loglike")
+        L.call(fn, "vbmp_quadform_loglike", L.ptr(X2), S, Bo, Bi, D, L.ptr(Pc), L.ptr(bc), L.ptr(cc), L.ptr(out), L.stream_ptr(dev))
     return out.reshape(sample_shape + mat_batch)
 
 
@@ -196,9 +194,8 @@ def mixture_estep(X, P, b, c):
     acc = torch.zeros(K + 1, dtype=dt, device=dev)
     if S > 0:
         fn = getattr(lib, "vbmp_mixture_estep_" + L.suffix(dt))
-        L.check(fn(L.ptr(Xc), S, K, D, L.ptr(P.contiguous()), L.ptr(b.contiguous()), L.ptr(c.contiguous()), L.ptr(p),
-                   L.ptr(acc), ctypes.c_void_p(acc.data_ptr() + K * acc.element_size()), L.stream_ptr(dev)),
-                "vbmp_mixture_estep")
+        L.call(fn, "vbmp_mixture_estep", L.ptr(Xc), S, K, D, L.ptr(P.contiguous()), L.ptr(b.contiguous()), L.ptr(c.contiguous()), L.ptr(p),
+                   L.ptr(acc), ctypes.c_void_p(acc.data_ptr() + K * acc.element_size()), L.stream_ptr(dev))
     return p, acc[:K], acc[K]
 
 
@@ -224,6 +221,5 @@ def weighted_moments(X, pv, n_sample_dims, mat_batch):
     Nk, SEx, SExx = buf[:nB], buf[nB:nB * (1 + D)], buf[nB * (1 + D):]
     if S > 0 and nB > 0:
         fn = getattr(lib, "vbmp_weighted_moments_" + L.suffix(dt))
-        L.check(fn(L.ptr(X2), L.ptr(p2), S, Bo, Bi, D, L.ptr(Nk), L.ptr(SEx), L.ptr(SExx), L.stream_ptr(dev)),
-                "vbmp_weighted_moments")
+        L.call(fn, "vbmp_weighted_moments", L.ptr(X2), L.ptr(p2), S, Bo, Bi, D, L.ptr(Nk), L.ptr(SEx), L.ptr(SExx), L.stream_ptr(dev))
     return Nk.reshape(mat_batch), SEx.reshape(mat_batch + (D,)), SExx.reshape(mat_batch + (D, D))
