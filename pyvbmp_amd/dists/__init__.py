@@ -3,5 +3,7 @@ the name of its submodule, so `import pyvbmp_amd.dists.Wishart as Wishart` yield
 from .Delta import Delta
 from .Dirichlet import Dirichlet
 from .Mixture import Mixture
+from .MultivariateNormal import MultivariateNormal
+from .MultivariateNormal_vector_format import MultivariateNormal_vector_format
 from .NormalInverseWishart import NormalInverseWishart
 from .Wishart import Wishart

@@ -27,10 +27,11 @@ def batch_operand(t, batch_shape, inner_shape):
     if tuple(t.shape) != full:
         t = t.expand(full)
     nb = len(batch_shape)
-    inner_dense = t[(0,) * nb].is_contiguous() if (nb and _prod(batch_shape) > 0) else t.is_contiguous()
     shared = all(t.stride(i) == 0 or t.shape[i] == 1 for i in range(nb))
-    if shared and inner_dense and nb > 0:
-        return t, 0
+    if shared and nb > 0 and _prod(batch_shape) > 0:
+        # one block for the whole batch: densify just that block (e.g. a scalar prior mean expanded
+        # over (B, D) has inner stride 0 too) and hand it to the kernel with batch stride 0
+        return t[(0,) * nb].contiguous(), 0
     t = t.contiguous()
     return t, _prod(inner_shape)
 
