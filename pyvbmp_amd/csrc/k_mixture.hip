@@ -120,9 +120,9 @@ __global__ __launch_bounds__(256) void k_mixture_estep(const T* __restrict__ X, 
 //   x = X[s,bi,:], w = p[s,bo,bi] (1 when p == NULL).  Outputs must be zeroed by the caller.
 // Block = 256 threads owns CH samples of one bi; thread t owns entries e = t, t+256, .. of the
 // (D*D + D + 1)-long statistic vector [xx^T | x | 1] for every bo.
-template <typename T, int CH>
+template <typename T>
 __global__ __launch_bounds__(256) void k_weighted_moments(const T* __restrict__ X, const T* __restrict__ p, int64_t S,
-                                                          int64_t Bo, int64_t Bi, int D, T* __restrict__ Nk,
+                                                          int64_t Bo, int64_t Bi, int D, int CH, T* __restrict__ Nk,
                                                           T* __restrict__ SEx, T* __restrict__ SExx) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* sx = reinterpret_cast<T*>(smem_raw);  // CH x (D+1), last column = 1
@@ -190,14 +190,16 @@ template <typename T>
 static int wmom_dispatch(const T* X, const T* p, int64_t S, int64_t Bo, int64_t Bi, int D, T* Nk, T* SEx, T* SExx,
                          void* stream) {
   if (S == 0 || Bo == 0 || Bi == 0) return 0;
-  if (!X || !Nk || !SEx || !SExx || S < 0 || Bo < 0 || Bi < 0 || D < 1 || D > VBMP_MAX_DIM || Bi > 65535)
+  if (!X || !Nk || !SEx || !SExx || S < 0 || Bo < 0 || Bi < 0 || D < 1 || D > 2 * VBMP_MAX_DIM || Bi > 65535)
     return VBMP_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  constexpr int CH = 256;
+  // samples per block: as many as fit a 48 KiB LDS image of [x | 1 | w] rows (at most 256)
+  int CH = (int)((48 * 1024) / ((size_t)(D + 2) * sizeof(T)));
+  CH = CH > 256 ? 256 : CH;
   const int64_t bx = (S + CH - 1) / CH;
   const size_t smem = (size_t)(CH * (D + 1) + CH) * sizeof(T);
-  hipLaunchKernelGGL((k_weighted_moments<T, CH>), dim3((unsigned)bx, (unsigned)Bi), dim3(256), smem, st, X, p, S, Bo,
-                     Bi, D, Nk, SEx, SExx);
+  hipLaunchKernelGGL((k_weighted_moments<T>), dim3((unsigned)bx, (unsigned)Bi), dim3(256), smem, st, X, p, S, Bo, Bi, D,
+                     CH, Nk, SEx, SExx);
   return hipGetLastError() == hipSuccess ? 0 : VBMP_ERR_LAUNCH;
 }
 

@@ -1,0 +1,412 @@
+"""Matrix-normal-Wishart node: conjugate Bayesian linear map  y = A x + noise  with A (n x p) matrix
+normal and the noise precision Wishart.  Same surface as the reference node
+(transforms/MatrixNormalWishart.py:8-471): constructor, ss_update / update / raw_update, the
+Elog_like* family, forward / backward messages, predict / postdict, KLqprior and the expectations.
+
+Where the arithmetic runs:
+  * sufficient statistics of update / raw_update: ONE K4 weighted-moment launch on the stacked vector
+    z = [x; y] gives SExx, SEyx, SEyy, SEx, SEy and N together (no broadcast (T,S,...,p,p) temporaries);
+  * every inverse / logdet (ss_update, forward, backward, Res): K1; the Wishart part: K2a;
+  * Elog_like / Elog_like_given_pX_pY: one K3a quadratic-form launch on z with the block precision
+    [[E[A'RA], -E[A'R]], [-E[RA], E[R]]];
+  * the remaining products are plain batched GEMMs (rocBLAS through torch.matmul).
+"""
+import math
+
+import torch
+
+from .. import ops
+from .._common import as_param, resolve
+from ..dists.MultivariateNormal_vector_format import MultivariateNormal_vector_format
+from ..dists.Wishart import Wishart
+from ..utils.matrix_utils import matrix_utils
+
+_LOG2PI = math.log(2.0 * math.pi)
+
+
+def _T(a):
+    return a.transpose(-2, -1)
+
+
+def _sq(a):
+    return a.squeeze(-1).squeeze(-1)
+
+
+def _cov_of(d):
+    """covariance of an input 'distribution' (None for observed data wrapped in Delta)"""
+    if hasattr(d, "ESigma"):
+        return d.ESigma()
+    return None
+
+
+class MatrixNormalWishart():
+    def __init__(self, event_shape, batch_shape=(), prior_parms=None, scale=1.0, mask=None, X_mask=None,
+                 pad_X=False, fixed_precision=False, device=None, dtype=None):
+        if prior_parms is None:
+            prior_parms = {'mu': 0.0}
+        self.device, self.dtype = resolve(device, dtype)
+        event_shape, batch_shape = tuple(event_shape), tuple(batch_shape)
+        self.n = event_shape[-2]
+        self.p = event_shape[-1]
+        self.pad_X = pad_X
+        self.fixed_precision = fixed_precision
+        mu_0 = as_param(prior_parms['mu'], self.device, self.dtype)
+        if pad_X:
+            self.p = self.p + 1
+            event_shape = event_shape[:-1] + (self.p,)
+            if mu_0.ndim != 0:
+                mu_0 = torch.cat((mu_0, mu_0.new_zeros(tuple(mu_0.shape[:-1]) + (1,))), dim=-1)
+        mu_0 = mu_0.expand(batch_shape + event_shape)
+        self.event_dim = len(event_shape)
+        self.event_shape = event_shape
+        self.batch_dim = len(batch_shape)
+        self.batch_shape = batch_shape
+
+        self.mask = None if mask is None else mask.to(self.device)
+        self.X_mask = None if X_mask is None else X_mask.to(self.device)
+        self.mu_0 = mu_0
+        self.mu = torch.randn(mu_0.shape, device=self.device, dtype=self.dtype) / math.sqrt(self.p) + mu_0
+
+        eye = torch.eye(self.p, device=self.device, dtype=self.dtype)
+        self.invV_0 = eye.expand(batch_shape + event_shape[:-2] + (self.p, self.p))
+        self.invV = self.invV_0
+        self.V = self.invV_0  # inverse of the identity
+        zeros = torch.zeros(batch_shape + event_shape[:-2], device=self.device, dtype=self.dtype)
+        self.logdetinvV = zeros
+        self.logdetinvV_0 = zeros
+
+        self.invU = Wishart(event_shape=event_shape[:-2] + (self.n, self.n), batch_shape=batch_shape, scale=scale,
+                            device=self.device, dtype=self.dtype)
+        self.SEyy = 0.0
+        self.SExx = 0.0
+        self.SEyx = 0.0
+        self.N = 0.0
+
+        if self.X_mask is not None:
+            if pad_X:
+                ones = torch.ones(tuple(self.X_mask.shape[:-1]) + (1,), dtype=torch.bool, device=self.device)
+                self.X_mask = torch.cat((self.X_mask, ones), dim=-1)
+            self.mu_0 = self.mu_0 * self.X_mask
+            self.mu = self.mu * self.X_mask
+            self.V = self.V * self.X_mask * _T(self.X_mask)
+            self.invV = self.invV * self.X_mask * _T(self.X_mask)
+        if self.mask is not None:
+            if pad_X:
+                ones = torch.ones(tuple(self.mask.shape[:-1]) + (1,), dtype=torch.bool, device=self.device)
+                self.mask = torch.cat((self.mask, ones), dim=-1)
+            self.mu_0 = self.mu_0 * self.mask
+            self.mu = self.mu * self.mask
+        self.log2pi = torch.tensor(_LOG2PI, device=self.device, dtype=self.dtype)
+
+    def to_event(self, n):
+        if n == 0:
+            return self
+        self.event_dim = self.event_dim + n
+        self.batch_dim = self.batch_dim - n
+        self.event_shape = self.batch_shape[-n:] + self.event_shape
+        self.batch_shape = self.batch_shape[:-n]
+        self.invU.to_event(n)
+        return self
+
+    # ------------------------------------------------------------------ conjugate update
+    def ss_update(self, SExx, SEyx, SEyy, N, lr=1.0, beta=None):
+        """Sufficient statistics -> posterior (ref transforms/MatrixNormalWishart.py:82-141)."""
+        assert (SExx.ndim == self.batch_dim + self.event_dim)
+        assert (SEyx.ndim == self.batch_dim + self.event_dim)
+        assert (SEyy.ndim == self.batch_dim + self.event_dim)
+        assert (N.ndim == self.batch_dim + self.event_dim - 2)
+        if beta is not None:
+            self.SExx = beta * self.SExx + SExx
+            self.SEyx = beta * self.SEyx + SEyx
+            self.SEyy = beta * self.SEyy + SEyy
+            self.N = beta * self.N + N
+            SExx, SEyx, SEyy, N = self.SExx, self.SEyx, self.SEyy, self.N
+
+        if self.X_mask is not None:
+            SExx = SExx * self.X_mask * _T(self.X_mask)
+            SEyx = SEyx * self.X_mask
+        invV = self.invV_0 + SExx
+        V_new = ops.spd_inverse(invV)
+        mu = (self.mu_0 @ self.invV_0 + SEyx) @ V_new
+        if self.X_mask is not None:
+            mu = mu * self.X_mask
+
+        if self.mask is not None:  # linear constraint on the posterior mean; same mask for the whole batch
+            U = ops.spd_inverse(self.invU.EinvSigma())
+            Astar = V_new.unsqueeze(-3).unsqueeze(-2) * U.unsqueeze(-2).unsqueeze(-1)
+            off = ~self.mask
+            A = Astar[..., off, :, :][..., :, off]
+            gamma = torch.zeros_like(mu)
+            gamma[..., off] = torch.linalg.solve(A, mu[..., off])
+            mu = (mu - U @ gamma @ V_new) * self.mask
+
+        if self.fixed_precision is False:
+            W_arg = SEyy - mu @ invV @ _T(mu) + self.mu_0 @ self.invV_0 @ _T(self.mu_0)
+            self.invU.ss_update(W_arg, N, lr=lr, beta=None)
+        invV = lr * invV + (1.0 - lr) * self.invV
+        self.invV = 0.5 * (invV + _T(invV))
+        self.mu = lr * mu + (1.0 - lr) * self.mu
+        if self.mask is not None:
+            self.mu = self.mu * self.mask
+        self.V, self.logdetinvV = ops.spd_inv_logdet(self.invV)
+        if self.X_mask is not None:
+            self.mu = self.mu * self.X_mask
+
+    def _moments(self, EX, EY, covX, covY, p):
+        """SExx, SEyx, SEyy, N (+ bias augmentation) from means / covariances / responsibilities."""
+        nd = self.event_dim + self.batch_dim
+        sample_shape = tuple(EX.shape[:EX.ndim - nd])
+        nsd = len(sample_shape)
+        mat_batch = self.batch_shape + self.event_shape[:-2]
+        full = sample_shape + mat_batch
+        px, n = EX.shape[-2], EY.shape[-2]
+        z = torch.cat((EX.expand(full + (px, 1)), EY.expand(full + (n, 1))), dim=-2).squeeze(-1)
+        pw = None if p is None else p.reshape(tuple(p.shape) + (1,) * (self.event_dim - 2))
+        N, Sz, Szz = ops.weighted_moments(z, pw, nsd, mat_batch)
+        SExx, SEyx, SEyy = Szz[..., :px, :px], Szz[..., px:, :px], Szz[..., px:, px:]
+        SEx, SEy = Sz[..., :px].unsqueeze(-1), Sz[..., px:].unsqueeze(-1)
+
+        def wsum(C):
+            if C is None:
+                return 0.0
+            if C.ndim <= len(mat_batch) + 2:  # no sample axes: shared by every sample
+                return C * N.reshape(tuple(N.shape) + (1, 1))
+            C = C.expand(full + tuple(C.shape[-2:]))
+            if pw is None:
+                return C.sum(tuple(range(nsd)))
+            w = pw.expand(full)
+            return (C * w.reshape(full + (1, 1))).sum(tuple(range(nsd)))
+
+        SExx = SExx + wsum(covX)
+        SEyy = SEyy + wsum(covY)
+        if self.pad_X:
+            SExx = torch.cat((SExx, SEx), dim=-1)
+            last = torch.cat((SEx, N.reshape(tuple(N.shape) + (1, 1))), dim=-2)
+            SExx = torch.cat((SExx, _T(last)), dim=-2)
+            SEyx = torch.cat((SEyx, SEy), dim=-1)
+        return SExx, SEyx, SEyy, N
+
+    def update(self, pX, pY, p=None, lr=1.0, beta=None):
+        """Input / output distributions (+ responsibilities) -> ss_update (ref :143-172)."""
+        SExx, SEyx, SEyy, N = self._moments(pX.EX(), pY.EX(), _cov_of(pX), _cov_of(pY), p)
+        self.ss_update(SExx, SEyx, SEyy, N, lr=lr, beta=beta)
+
+    def raw_update(self, X, Y, p=None, lr=1.0, beta=None):
+        """Data (+ responsibilities) -> ss_update (ref :174-204)."""
+        SExx, SEyx, SEyy, N = self._moments(X, Y, None, None, p)
+        self.ss_update(SExx, SEyx, SEyy, N, lr=lr, beta=beta)
+
+    def KLqprior(self):
+        KL = self.n / 2.0 * self.logdetinvV - self.n / 2.0 * self.logdetinvV_0 - self.n * self.p / 2.0
+        if self.X_mask is not None:
+            KL = KL + self.n / 2.0 * self.logdetinvV_0 * (self.X_mask).sum((-1, -2))
+        KL = KL + 0.5 * self.n * (self.invV_0 * self.V).sum((-1, -2))
+        d = self.mu - self.mu_0
+        KL = KL + 0.5 * (self.invV_0 * (_T(d) @ self.invU.EinvSigma() @ d)).sum((-1, -2))
+        for i in range(self.event_dim - 2):
+            KL = KL.sum(-1)
+        return KL + self.invU.KLqprior()
+
+    # ------------------------------------------------------------------ likelihoods
+    def _joint_quadratic(self):
+        """(P, b, c): Elog_like(x, y) = -1/2 z^T P z + z^T b + c with z = [x; y] (bias column folded in)."""
+        R, G, H = self.EinvSigma(), self.EinvUX(), self.EXTinvUX()
+        c = 0.5 * self.ElogdetinvSigma() - 0.5 * self.n * _LOG2PI
+        if self.pad_X:
+            H11, G1 = H[..., :-1, :-1], G[..., :, :-1]
+            b = torch.cat((-H[..., :-1, -1], G[..., :, -1]), dim=-1)
+            c = c - 0.5 * H[..., -1, -1]
+        else:
+            H11, G1 = H, G
+            b = torch.zeros(tuple(c.shape) + (self.p + self.n,), device=self.device, dtype=self.dtype)
+        P = torch.cat((torch.cat((H11, -_T(G1)), dim=-1), torch.cat((-G1, R), dim=-1)), dim=-2)
+        return P, b, c
+
+    def _stack(self, X, Y):
+        lead = torch.broadcast_shapes(X.shape[:-2], Y.shape[:-2])
+        return torch.cat((X.expand(lead + tuple(X.shape[-2:])), Y.expand(lead + tuple(Y.shape[-2:]))), dim=-2).squeeze(-1)
+
+    def Elog_like(self, X, Y):
+        P, b, c = self._joint_quadratic()
+        ELL = ops.quadform_loglike(self._stack(X, Y), P, b, c)
+        for i in range(self.event_dim - 2):
+            ELL = ELL.sum(-1)
+        return ELL
+
+    def Elog_like_given_pX_pY(self, pX, pY):
+        P, b, c = self._joint_quadratic()
+        ELL = ops.quadform_loglike(self._stack(pX.mean(), pY.mean()), P, b, c)
+        px = self.p - 1 if self.pad_X else self.p
+        cx, cy = _cov_of(pX), _cov_of(pY)
+        if cx is not None:
+            ELL = ELL - 0.5 * (cx * P[..., :px, :px]).sum((-1, -2))
+        if cy is not None:
+            ELL = ELL - 0.5 * (cy * P[..., px:, px:]).sum((-1, -2))
+        for i in range(self.event_dim - 2):
+            ELL = ELL.sum(-1)
+        return ELL
+
+    def _residual_y(self, Y):
+        """-1/2 y' E[R] y - n/2 log 2pi + 1/2 E log|R|  (one K3a launch)"""
+        R = self.EinvSigma()
+        c = 0.5 * self.ElogdetinvSigma() - 0.5 * self.n * _LOG2PI
+        zero = torch.zeros(tuple(c.shape) + (self.n,), device=self.device, dtype=self.dtype)
+        return ops.quadform_loglike(Y.squeeze(-1), R, zero, c)
+
+    def Elog_like_X(self, Y):
+        H, Gt = self.EXTinvUX(), self.EXTinvU()
+        Residual = self._residual_y(Y)
+        if self.pad_X:
+            return H[..., :-1, :-1], Gt[..., :-1, :] @ Y - H[..., :-1, -1:], Residual - 0.5 * H[..., -1, -1]
+        return H, Gt @ Y, Residual
+
+    def _joint_blocks(self, pY, bias_sign):
+        R, G, H = self.EinvSigma(), self.EinvUX(), self.EXTinvUX()
+        Jyy = pY.EinvSigma() + R
+        if self.pad_X:
+            return (Jyy, -G[..., :, :-1], H[..., :-1, :-1], pY.EinvSigmamu() + bias_sign * G[..., :, -1:],
+                    -H[..., :-1, -1:], H[..., -1, -1])
+        zero = torch.zeros(tuple(H.shape[:-1]) + (1,), device=self.device, dtype=self.dtype)
+        return Jyy, -G, H, pY.EinvSigmamu(), zero, torch.zeros((), device=self.device, dtype=self.dtype)
+
+    def _marginalise(self, pY, bias_sign, Res0):
+        Jyy, Jyx, Jxx, jy, jx, J11 = self._joint_blocks(pY, bias_sign)
+        Pyy, nBiD, nCiA, Pxx = matrix_utils.block_precision_marginalizer(Jyy, Jyx, _T(Jyx), Jxx)
+        eta_y = jy + nBiD @ jx
+        eta_x = jx + nCiA @ jy
+        Syy, ld_yy = ops.spd_inv_logdet(Pyy)
+        Res = Res0 + pY.Res() + 0.5 * _sq(_T(eta_y) @ Syy @ eta_y) - 0.5 * ld_yy + 0.5 * pY.dim * _LOG2PI \
+            + 0.5 * self.ElogdetinvSigma() - 0.5 * J11
+        return Pxx, eta_x, Res
+
+    def Elog_like_X_given_pY(self, pY):
+        Pxx, eta_x, Res = self._marginalise(pY, -1.0, 0.0)
+        Sxx, ld = ops.spd_inv_logdet(Pxx)
+        px = MultivariateNormal_vector_format(invSigma=Pxx, invSigmamu=eta_x, mu=Sxx @ eta_x, Sigma=Sxx,
+                                              logdetinvSigma=ld)
+        return px, Res - px.Res()
+
+    # ------------------------------------------------------------------ messages
+    def Eforward(self, pX):
+        G = self.EinvUX()
+        eta = G[..., :, :-1] @ pX.mean()
+        if self.pad_X:
+            eta = eta + G[..., :, -1:]
+        return MultivariateNormal_vector_format(invSigma=self.EinvSigma(), invSigmamu=eta)
+
+    def forward(self, pX):
+        """Message x -> y for a Gaussian input (ref :303-328): returns (MVN_vf(mu, Sigma), Res)."""
+        Px, etax = pX.EinvSigma(), pX.EinvSigmamu()
+        nV, M = self.n * self.V, self.mean()
+        Sx, ld_x = ops.spd_inv_logdet(Px)
+        if self.pad_X:
+            nV11, eta, M1 = nV[..., :-1, :-1], etax - nV[..., :-1, -1:], M[..., :-1]
+        else:
+            nV11, eta, M1 = nV, etax, M
+        S, ld_s = ops.spd_inv_logdet(nV11 + Px)
+        mu_y = M1 @ (S @ eta)
+        if self.pad_X:
+            mu_y = mu_y + M[..., -1:]
+        Sigma_yy = M1 @ S @ _T(M1) + self.invEinvSigma()
+        # -1/2 mu_x' P mu_x = -1/2 eta_x' P^-1 eta_x ;  logdet(nV P^-1 + I) = logdet(nV + P) - logdet P
+        Res = -0.5 * _sq(_T(etax) @ Sx @ etax) + 0.5 * _sq(_T(eta) @ S @ eta) - 0.5 * (ld_s - ld_x)
+        if self.pad_X:
+            Res = Res - 0.5 * nV[..., -1, -1]
+        return MultivariateNormal_vector_format(mu=mu_y, Sigma=Sigma_yy), Res
+
+    def backward(self, pY, Res=0.0):
+        """Message y -> x (ref :352-375): returns (MVN_vf(invSigma, invSigmamu), Res)."""
+        Pxx, eta_x, R = self._marginalise(pY, +1.0, Res)
+        pX = MultivariateNormal_vector_format(invSigma=Pxx, invSigmamu=eta_x)
+        return pX, R - pX.Res()
+
+    def Ebackward(self, pY):
+        raise NotImplementedError
+
+    def predict(self, X):
+        G, H = self.EinvUX(), self.EXTinvUX()
+        c = 0.5 * self.ElogdetinvSigma() - 0.5 * self.n * _LOG2PI
+        if self.pad_X:
+            eta = G[..., :, :-1] @ X + G[..., :, -1:]
+            P, b, c = H[..., :-1, :-1], -H[..., :-1, -1], c - 0.5 * H[..., -1, -1]
+        else:
+            eta = G @ X
+            P, b = H, torch.zeros(tuple(c.shape) + (self.p,), device=self.device, dtype=self.dtype)
+        Res = ops.quadform_loglike(X.squeeze(-1).expand(tuple(eta.shape[:-2]) + (X.shape[-2],)), P, b, c)
+        pY = MultivariateNormal_vector_format(invSigma=self.EinvSigma(), invSigmamu=eta)
+        return pY, Res - pY.Res()
+
+    def postdict(self, Y):
+        P, eta, Residual = self.Elog_like_X(Y)
+        pX = MultivariateNormal_vector_format(invSigma=P, invSigmamu=eta)
+        return pX, Residual - pX.Res()
+
+    def predict_given_pX(self, pX):
+        return self.forward(pX)
+
+    # ------------------------------------------------------------------ expectations
+    def mean(self):
+        return self.mu
+
+    def bias(self):
+        return self.mu[..., -1:] if self.pad_X is True else torch.tensor(0.0, device=self.device, dtype=self.dtype)
+
+    def weights(self):
+        return self.mu[..., :-1] if self.pad_X is True else self.mu
+
+    def var(self):
+        return self.ESigma().diagonal(dim1=-1, dim2=-2).unsqueeze(-1) * self.V.diagonal(dim1=-1, dim2=-2).unsqueeze(-2)
+
+    def EinvUX(self):
+        return self.invU.EinvSigma() @ self.mu
+
+    def EXTinvU(self):
+        return _T(self.mu) @ self.invU.EinvSigma()
+
+    def EXTAX(self, A):
+        return self.V * (self.invU.ESigma() * A).sum((-1, -2)) + _T(self.mu) @ A @ self.mu
+
+    def EXmMUTAXmMU(self, A):
+        return self.V * (self.invU.ESigma() * A).sum((-1, -2))
+
+    def EXAXT(self, A):
+        return self.ESigma() * (self.V * A).sum((-1, -2)) + self.mu @ A @ _T(self.mu)
+
+    def EXmMUAXmMUT(self, A):
+        return self.ESigma() * (self.V * A).sum((-1, -2))
+
+    def EXTinvUX(self):
+        return self.n * self.V + _T(self.mu) @ self.invU.EinvSigma() @ self.mu
+
+    def EXinvVXT(self):
+        return self.p * self.invU.ESigma() + self.mu @ self.invV @ _T(self.mu)
+
+    def EXmMUTinvUXmMU(self):
+        return self.n * self.V
+
+    def EXmMUinvVXmMUT(self):
+        return self.p * self.invU.ESigma()
+
+    def EXTX(self):
+        return self.V * self.invU.ESigma().diagonal().sum() + _T(self.mu) @ self.mu
+
+    def EXXT(self):
+        return self.V.diagonal().sum() * self.invU.ESigma() + self.mu @ _T(self.mu)
+
+    def ElogdetinvU(self):
+        return self.invU.ElogdetinvSigma()
+
+    def logdetEinvSigma(self):
+        return self.invU.logdetEinvSigma()
+
+    def ElogdetinvSigma(self):
+        return self.invU.ElogdetinvSigma()
+
+    def EinvSigma(self):
+        return self.invU.EinvSigma()
+
+    def invEinvSigma(self):
+        return self.invU.invEinvSigma()
+
+    def ESigma(self):
+        return self.invU.ESigma()

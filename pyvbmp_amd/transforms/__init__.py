@@ -1,0 +1,3 @@
+"""Transform nodes; each class re-exported under its submodule name, as in the reference
+(transforms/__init__.py:1-13)."""
+from .MatrixNormalWishart import MatrixNormalWishart

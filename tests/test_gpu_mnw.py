@@ -1,0 +1,129 @@
+"""GPU parity of MatrixNormalWishart (updates, likelihoods, forward / backward messages) against golden
+fixtures captured from the reference."""
+import pytest
+import torch
+
+from tests.helpers import TOL64, assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+MNW_CASES = ["mnw_4x3_b5", "mnw_4x3_b5_pad", "mnw_4x3_nobatch", "mnw_32x32", "mnw_6x7_b2_pad"]
+
+
+def _make(c):
+    from pyvbmp_amd.transforms import MatrixNormalWishart
+    batch = tuple(int(v) for v in c["batch_shape"])
+    mask = c["mask"].to(DEV) if "mask" in c else None
+    X_mask = c["X_mask"].to(DEV) if "X_mask" in c else None
+    m = MatrixNormalWishart((int(c["n"]), int(c["p"])), batch, pad_X=bool(int(c["pad_X"])), mask=mask, X_mask=X_mask,
+                            device=DEV, dtype=torch.float64)
+    m.mu = c["init_mu"].to(DEV)
+    return m, batch
+
+
+def _check(m, c, pre, tol=TOL64):
+    for f in ("mu", "invV", "V", "logdetinvV"):
+        assert_close(getattr(m, f), c[pre + f], tol, what=pre + f)
+    for f in ("invU", "U", "nu", "logdet_invU"):
+        assert_close(getattr(m.invU, f), c[pre + "invU_" + f], tol, what=pre + "invU_" + f)
+
+
+def _vf(**kw):
+    from pyvbmp_amd.dists import MultivariateNormal_vector_format
+    return MultivariateNormal_vector_format(**{k: v.to(DEV).clone() for k, v in kw.items()})
+
+
+@pytest.mark.parametrize("case", MNW_CASES)
+def test_mnw_golden(golden, case):
+    from pyvbmp_amd.dists import Delta
+    c = golden("mnw")[case]
+    m, batch = _make(c)
+    X, Y = c["X"].to(DEV), c["Y"].to(DEV)
+    pr = c["p_resp"].to(DEV) if "p_resp" in c else None
+    N = X.shape[0]
+    Xe = X.expand((N,) + batch + tuple(X.shape[-2:]))
+    m.raw_update(Xe, Y, p=pr, lr=1.0)
+    _check(m, c, "raw1_")
+    m.raw_update(Xe, Y, p=pr, lr=0.5)
+    _check(m, c, "raw2_")
+    for f in ("EinvUX", "EXTinvU", "EXTinvUX", "EXinvVXT", "EXmMUTinvUXmMU", "EXmMUinvVXmMUT", "ElogdetinvU",
+              "logdetEinvSigma", "ElogdetinvSigma", "EinvSigma", "invEinvSigma", "ESigma", "KLqprior", "mean",
+              "weights", "var"):
+        assert_close(getattr(m, f)(), c["raw2_" + f], what=f)
+    if "raw2_EXTX" in c:
+        assert_close(m.EXTX(), c["raw2_EXTX"])
+        assert_close(m.EXXT(), c["raw2_EXXT"])
+        A = torch.eye(m.p, dtype=torch.float64, device=DEV) * 0.5 + 0.1
+        An = torch.eye(m.n, dtype=torch.float64, device=DEV) * 0.5 + 0.1
+        assert_close(m.EXTAX(An), c["raw2_EXTAX"])
+        assert_close(m.EXAXT(A), c["raw2_EXAXT"])
+    assert_close(m.Elog_like(X, Y), c["Elog_like"], what="Elog_like")
+    P, eta, R = m.Elog_like_X(Y)
+    assert_close(P, c["ELX_invSigma"])
+    assert_close(eta, c["ELX_invSigmamu"])
+    assert_close(R, c["ELX_Res"], what="ELX Res")
+    pY, R = m.predict(X)
+    assert_close(pY.invSigma, c["predict_invSigma"])
+    assert_close(pY.invSigmamu, c["predict_invSigmamu"])
+    assert_close(R, c["predict_Res"], what="predict Res")
+    pX, R = m.postdict(Y)
+    assert_close(pX.invSigma, c["postdict_invSigma"])
+    assert_close(pX.invSigmamu, c["postdict_invSigmamu"])
+    assert_close(R, c["postdict_Res"], what="postdict Res")
+
+    # messages: per-sample precision (BASELINE config 3 shape) and shared precision
+    pYm, R = m.forward(_vf(invSigma=c["fw_in_invSigma"], invSigmamu=c["fw_in_invSigmamu"]))
+    assert_close(pYm.mu, c["fw_mu"], what="fw mu")
+    assert_close(pYm.Sigma, c["fw_Sigma"], what="fw Sigma")
+    assert_close(R, c["fw_Res"], what="fw Res")
+    pYs, R = m.forward(_vf(invSigma=c["fws_in_invSigma"], invSigmamu=c["fw_in_invSigmamu"]))
+    assert_close(pYs.mu, c["fws_mu"], what="fws mu")
+    assert_close(pYs.Sigma, c["fws_Sigma"], what="fws Sigma")
+    assert_close(R, c["fws_Res"], what="fws Res")
+    pXb, R = m.backward(_vf(invSigma=c["bw_in_invSigma"], invSigmamu=c["bw_in_invSigmamu"]))
+    assert_close(pXb.invSigma, c["bw_invSigma"], what="bw P")
+    assert_close(pXb.invSigmamu, c["bw_invSigmamu"], what="bw eta")
+    assert_close(R, c["bw_Res"], what="bw Res")
+    pXs, R = m.backward(_vf(invSigma=c["bws_in_invSigma"], invSigmamu=c["bw_in_invSigmamu"]), Res=0.25)
+    assert_close(pXs.invSigma, c["bws_invSigma"], what="bws P")
+    assert_close(pXs.invSigmamu, c["bws_invSigmamu"], what="bws eta")
+    assert_close(R, c["bws_Res"], what="bws Res")
+    px, R = m.Elog_like_X_given_pY(_vf(invSigma=c["bw_in_invSigma"], invSigmamu=c["bw_in_invSigmamu"]))
+    assert_close(px.invSigma, c["ELXpY_invSigma"])
+    assert_close(px.invSigmamu, c["ELXpY_invSigmamu"])
+    assert_close(px.mu, c["ELXpY_mu"])
+    assert_close(px.Sigma, c["ELXpY_Sigma"])
+    assert_close(R, c["ELXpY_Res"], what="ELXpY Res")
+
+    # update from distributions
+    pxd = c["upd_x_mu"].shape[-2]
+    ux_mu = c["upd_x_mu"].to(DEV).expand((N,) + batch + (pxd, 1)).clone()
+    ux_S = c["upd_x_Sigma"].to(DEV).expand((N,) + batch + (pxd, pxd)).clone()
+    from pyvbmp_amd.dists import MultivariateNormal_vector_format as VF
+    pXu = VF(mu=ux_mu, Sigma=ux_S)
+    assert_close(m.Elog_like_given_pX_pY(pXu, Delta(Y)), c["ELpXpY"], what="ELpXpY")
+    m.update(pXu, Delta(Y), p=pr, lr=0.8)
+    _check(m, c, "upd_")
+    n = int(c["n"])
+    pYu = VF(mu=Y.clone(), Sigma=c["upd_y_Sigma"].to(DEV).expand((N,) + batch + (n, n)).clone())
+    m.update(pXu, pYu, p=pr, lr=1.0, beta=0.5)
+    _check(m, c, "upd2_")
+    m.update(pXu, pYu, p=pr, lr=1.0, beta=0.5)
+    _check(m, c, "upd3_")
+    assert_close(m.KLqprior(), c["KLqprior_end"], what="KL end")
+
+
+@pytest.mark.parametrize("case", ["mnw_Xmask", "mnw_mask", "mnw_mask_pad"])
+def test_mnw_masks_golden(golden, case):
+    c = golden("mnw")[case]
+    m, batch = _make(c)
+    assert_close(m.mu_0, c["init_mu_0"])
+    X, Y, pr = c["X"].to(DEV), c["Y"].to(DEV), c["p_resp"].to(DEV)
+    Xe = X.expand((X.shape[0],) + batch + tuple(X.shape[-2:]))
+    m.raw_update(Xe, Y, p=pr, lr=1.0)
+    _check(m, c, "raw1_")
+    m.raw_update(Xe, Y, p=pr, lr=0.5)
+    _check(m, c, "raw2_")
+    assert_close(m.KLqprior(), c["KLqprior"], what="KL")
+    assert_close(m.Elog_like(X, Y), c["Elog_like"], what="Elog_like")
