@@ -25,6 +25,9 @@ class Mixture():
         self.pi = Dirichlet(event_shape=event_shape, batch_shape=self.batch_shape, prior_parms=prior_parms,
                             device=self.device, dtype=self.dtype)
         self.dist = dist
+        # set to a pyvbmp_amd.parallel.SuffStatReducer when the SAMPLE axis is sharded over ranks: the
+        # statistics of one VB iteration (NA, logZ, N, SEx, SExx) then cross ranks in one all-reduce
+        self.reducer = None
         self.logZ = torch.tensor(-torch.inf, device=self.device, dtype=self.dtype)
         self.ELBO_last = torch.tensor(-torch.inf, device=self.device, dtype=self.dtype)
 
@@ -67,11 +70,24 @@ class Mixture():
     def raw_update(self, X, iters=1, lr=1.0, verbose=False):
         self.update(X, iters=iters, lr=lr, verbose=verbose)
 
+    def _update_sharded(self, X, lr):
+        """One VB iteration when each rank holds a slice of the samples (case 2)."""
+        self.update_assignments(X)  # local responsibilities, local NA / logZ
+        SExx, SEx, N = self.dist.raw_moments(self._view(X), self.p)
+        self.NA, self.logZ, N, SEx, SExx = self.reducer.all_reduce([self.NA, self.logZ, N, SEx, SExx])
+        ELBO = self.ELBO()
+        self.pi.ss_update(self.NA, lr=lr)
+        self.dist.ss_update(SExx, SEx, N, lr, None)
+        return ELBO
+
     def update(self, X, iters=1, lr=1.0, verbose=False):
         for i in range(iters):
-            self.update_assignments(X)
-            ELBO = self.ELBO()
-            self.update_parms(X, lr)
+            if self.reducer is not None:
+                ELBO = self._update_sharded(X, lr)
+            else:
+                self.update_assignments(X)
+                ELBO = self.ELBO()
+                self.update_parms(X, lr)
             if verbose:
                 print('Percent Change in ELBO:   ', (ELBO - self.ELBO_last) / self.ELBO_last.abs() * 100.0)
             self.ELBO_last = ELBO

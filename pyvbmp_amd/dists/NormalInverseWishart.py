@@ -98,6 +98,11 @@ class NormalInverseWishart():
 
     def raw_update(self, X, p=None, lr=1.0, beta=None):
         """Data (+ responsibilities) -> sufficient statistics -> ss_update (ref :70-86)."""
+        SExx, SEx, N = self.raw_moments(X, p)
+        self.ss_update(SExx, SEx, N, lr, beta)
+
+    def raw_moments(self, X, p=None):
+        """(SExx, SEx, N) of raw_update without applying them (sample-sharded runs all-reduce these)."""
         nd = self.event_dim + self.batch_dim
         sample_shape = tuple(X.shape[:X.ndim - nd])
         mat_batch = self.batch_shape + self.event_shape[:-1]
@@ -107,7 +112,7 @@ class NormalInverseWishart():
             pv = p.reshape(tuple(p.shape) + (1,) * (self.event_dim - 1))
             N, SEx, SExx = ops.weighted_moments(X, pv, len(sample_shape), mat_batch)
             N = collapse_to(N, self.batch_shape + (1,) * (self.event_dim - 1))
-        self.ss_update(SExx, SEx, N, lr, beta)
+        return SExx, SEx, N
 
     def update(self, pX, p=None, lr=1.0, beta=None):
         pass

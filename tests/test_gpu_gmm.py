@@ -105,3 +105,73 @@ def test_weighted_moments_linearity_large():
     ref = torch.einsum("nk,ni,nj->kij", p[:100000], X[:100000, 0], X[:100000, 0])
     Q, = ops.weighted_moments(X[:100000], p[:100000], 1, (K,))[2:]
     assert_close(Q, ref, 1e-11)
+
+
+def test_gmm_sample_sharded_matches_single(golden):
+    """Mixture._update_sharded: two 'ranks' (threads sharing the GPU, a barrier-based stand-in for the
+    all-reduce) each hold half of the samples; the result must equal the unsharded run."""
+    import threading
+
+    from pyvbmp_amd.models import GaussianMixtureModel
+    K, D, N = 4, 16, 6000
+    g = torch.Generator().manual_seed(5)
+    centers = 3.0 * torch.randn(K, D, generator=g, dtype=torch.float64)
+    X = (centers[torch.randint(K, (N,), generator=g)] + torch.randn(N, D, generator=g, dtype=torch.float64)).to(DEV)
+    mu0 = (centers + 0.2).to(DEV)
+
+    def make():
+        m = GaussianMixtureModel(K, D, device=DEV, dtype=torch.float64)
+        m.dist.mu = mu0.clone()
+        m.pi.alpha = torch.full((K,), 0.7, dtype=torch.float64, device=DEV)
+        return m
+
+    ref = make()
+    ref.update(X, iters=3, lr=1.0)
+
+    class PairReducer:
+        def __init__(self):
+            self.bar = threading.Barrier(2)
+            self.slots = [None, None]
+            self.calls = 0
+
+        def all_reduce(self, rank, tensors):
+            self.slots[rank] = [t.clone() for t in tensors]
+            self.bar.wait()
+            out = [a + b for a, b in zip(*self.slots)]
+            self.bar.wait()
+            return out
+
+    shared = PairReducer()
+
+    class RankView:
+        def __init__(self, rank):
+            self.rank = rank
+            self.calls = 0
+
+        def all_reduce(self, tensors):
+            self.calls += 1
+            return shared.all_reduce(self.rank, tensors)
+
+    models, errs = [make(), make()], []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            m = models[rank]
+            m.reducer = RankView(rank)
+            m.update(X[rank * N // 2:(rank + 1) * N // 2], iters=3, lr=1.0)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+            shared.bar.abort()
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for m in models:
+        assert m.reducer.calls == 3  # one collective per VB iteration
+        assert_close(m.dist.mu, ref.dist.mu, 1e-10)
+        assert_close(m.dist.invU.invU, ref.dist.invU.invU, 1e-10)
+        assert_close(m.dist.invU.U, ref.dist.invU.U, 1e-10)
+        assert_close(m.pi.alpha, ref.pi.alpha, 1e-10)
+        assert_close(m.logZ, ref.logZ, 1e-10)
