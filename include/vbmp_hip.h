@@ -112,6 +112,38 @@ int vbmp_weighted_moments_f64(const double* X, const double* p, int64_t S, int64
 int vbmp_weighted_moments_f32(const float* X, const float* p, int64_t S, int64_t Bo, int64_t Bi, int D, float* Nk,
                               float* SEx, float* SExx, void* stream);
 
+/* K9 -- linear-dynamical-system E-step: information filter + smoother over T time steps for S independent
+ * series in ONE persistent launch (LinearDynamicalSystems.forward_backward_loop with forward_step /
+ * backward_step / forward_backward_combiner, models/LinearDynamicalSystems.py:268-383, including the
+ * reference's slot convention: Sigma_t_tp1[T-1] holds the (x0, x_0) cross term, and its elementwise `*` at :372).
+ * Hidden dimension 1 <= H <= VBMP_LDS_MAX_H.  Series s belongs to batch element b = s % NB (sample axes lead).
+ * Per-batch system parameters are dense (NB, ...).  Per-step inputs are addressed as
+ *     base + t*st_t + (s / NB)*st_s + (s % NB)*st_b          (strides in ELEMENTS, 0 = shared),
+ * so a likelihood precision that does not depend on time or sample is passed once (st_t = st_s = 0).
+ * cu1 = QA_xp_u U[t], cu2 = ATQA_x_u U[t] (H-vectors) and cu3 = U[t]' ATQA_u_u U[t] carry the control input.
+ * x0_res = -1/2 EXTinvUX + 1/2 ElogdetinvSigma - H/2 log 2pi of the initial-state prior (:349).
+ * Outputs are dense: invSigma/Sigma/Sigma_t_tp1 (T,S,H,H), invSigmamu/mu (T,S,H), logZ (T,S),
+ * Sigma_x0_x0 (S,H,H), mu_x0 (S,H).  All blocks must be 16-byte aligned. */
+#define VBMP_LDS_MAX_H 8
+#define VBMP_DECL_LDS_ARGS(SUF, REAL)                                                                         \
+  typedef struct vbmp_lds_args_##SUF {                                                                     \
+    int64_t T, S, NB;                                                                                      \
+    int H;                                                                                                 \
+    const REAL *invQ, *ATQA_xx, *QA_xp_x, *A_Elogdet; /* (NB,H,H) x3, (NB) */                                 \
+    const REAL *x0_P, *x0_eta, *x0_res;                /* (NB,H,H), (NB,H), (NB) */                           \
+    const REAL* like_P;   int64_t lP_t, lP_s, lP_b;                                                           \
+    const REAL* like_eta; int64_t le_t, le_s, le_b;                                                           \
+    const REAL* like_res; int64_t lr_t, lr_s, lr_b;                                                           \
+    const REAL* cu1;      int64_t c1_t, c1_s, c1_b;                                                           \
+    const REAL* cu2;      int64_t c2_t, c2_s, c2_b;                                                           \
+    const REAL* cu3;      int64_t c3_t, c3_s, c3_b;                                                           \
+    REAL *invSigma, *invSigmamu, *Sigma, *mu, *Sigma_t_tp1, *logZ, *Sigma_x0_x0, *mu_x0;                      \
+  } vbmp_lds_args_##SUF;
+VBMP_DECL_LDS_ARGS(f64, double)
+VBMP_DECL_LDS_ARGS(f32, float)
+int vbmp_lds_smoother_f64(const vbmp_lds_args_f64* args, void* stream);
+int vbmp_lds_smoother_f32(const vbmp_lds_args_f32* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

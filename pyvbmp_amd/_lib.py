@@ -52,6 +52,25 @@ def _sig_wmom(T):
     return [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr]
 
 
+def lds_args_struct(cT):
+    """ctypes mirror of vbmp_lds_args_{f64,f32} (include/vbmp_hip.h)."""
+    P = _c_ptr
+    fields = [("T", _c_i64), ("S", _c_i64), ("NB", _c_i64), ("H", _c_int)]
+    fields += [(n, P) for n in ("invQ", "ATQA_xx", "QA_xp_x", "A_Elogdet", "x0_P", "x0_eta", "x0_res")]
+    for n, pre in (("like_P", "lP"), ("like_eta", "le"), ("like_res", "lr"), ("cu1", "c1"), ("cu2", "c2"), ("cu3", "c3")):
+        fields += [(n, P), (pre + "_t", _c_i64), (pre + "_s", _c_i64), (pre + "_b", _c_i64)]
+    fields += [(n, P) for n in ("invSigma", "invSigmamu", "Sigma", "mu", "Sigma_t_tp1", "logZ", "Sigma_x0_x0", "mu_x0")]
+    return type("vbmp_lds_args", (ctypes.Structure,), {"_fields_": fields})
+
+
+LDS_ARGS = {"f64": lds_args_struct(ctypes.c_double), "f32": lds_args_struct(ctypes.c_float)}
+LDS_MAX_H = 8
+
+
+def _sig_lds(T):
+    return [_c_ptr, _c_ptr]  # const vbmp_lds_args_*: passed byref, stream
+
+
 # symbol -> argtypes builder.  Every symbol declared in include/vbmp_hip.h appears here
 # (tests/test_cabi.py cross-checks the header against this table and against the .so).
 SYMBOLS = {
@@ -61,6 +80,7 @@ SYMBOLS = {
     "vbmp_quadform_loglike": _sig_quadform,
     "vbmp_mixture_estep": _sig_estep,
     "vbmp_weighted_moments": _sig_wmom,
+    "vbmp_lds_smoother": _sig_lds,
 }
 DTYPES = {"f64": (torch.float64, ctypes.c_double), "f32": (torch.float32, ctypes.c_float)}
 

@@ -1,0 +1,255 @@
+"""Variational-Bayes linear dynamical system
+       x_t = A [x_{t-1}; u_t] + eta_t ,   y_t = B [x_t; r_t] + eps_t
+with the same surface as the reference model (models/LinearDynamicalSystems.py:14-383): constructor,
+reshape_inputs, update, ss_update, update_latents, forward_backward_loop, ELBO, KLqprior, attributes
+px (MultivariateNormal_vector_format), SE_*, T, N, logZ.
+
+E-step: the whole information filter + smoother (the reference's Python loops over T, :358-381) is ONE
+persistent HIP launch (K9): series-parallel, time-sequential, h x h state in registers.
+M-step: x0.ss_update (K2), A.ss_update / obs_model.ss_update (MatrixNormalWishart: K1 + K2a).
+
+Only latent_noise='shared' (MatrixNormalWishart transition) is on the accelerated path; the reference's
+default transition (MatrixNormalGamma, diagonal noise) is the first "next" row of SURVEY.md 8(f).
+"""
+import math
+
+import torch
+
+from .. import ops
+from .._common import resolve
+from ..dists.MultivariateNormal_vector_format import MultivariateNormal_vector_format
+from ..dists.NormalInverseWishart import NormalInverseWishart
+from ..transforms.MatrixNormalWishart import MatrixNormalWishart
+
+_LOG2PI = math.log(2.0 * math.pi)
+
+
+def _T(a):
+    return a.transpose(-2, -1)
+
+
+class LinearDynamicalSystems():
+    def __init__(self, obs_shape, hidden_dim, control_dim=0, regression_dim=0, obs_model=None,
+                 latent_noise='independent', batch_shape=(), A_mask=None, B_mask=None, device=None, dtype=None):
+        if latent_noise != 'shared':
+            raise NotImplementedError("latent_noise=%r uses MatrixNormalGamma (diagonal transition noise), which is not "
+                                      "on the accelerated path yet; use latent_noise='shared'" % (latent_noise,))
+        self.device, self.dtype = resolve(device, dtype)
+        control_dim = control_dim + 1
+        regression_dim = regression_dim + 1
+        obs_shape, batch_shape = tuple(obs_shape), tuple(batch_shape)
+        self.obs_shape = obs_shape
+        self.obs_dim = obs_shape[-1]
+        self.hidden_dim = hidden_dim
+        self.latent_noise = latent_noise
+        self.batch_shape = batch_shape
+        self.batch_dim = len(batch_shape)
+        self.control_dim = control_dim
+        self.regression_dim = regression_dim
+        self.event_dim = len(obs_shape)
+        self.logZ = torch.tensor(0.0, device=self.device, dtype=self.dtype)
+        kw = {"device": self.device, "dtype": self.dtype}
+
+        def pad_mask(m):
+            if m is None:
+                return None
+            m = m.to(self.device)
+            return torch.cat((m, torch.ones(tuple(m.shape[:-1]) + (1,), dtype=torch.bool, device=self.device)), dim=-1)
+        A_mask, B_mask = pad_mask(A_mask), pad_mask(B_mask)
+        self.offset = (1,) * (len(obs_shape) - 1)
+        self.expand_to_batch = False
+        self.x0 = NormalInverseWishart(self.offset + (hidden_dim,), batch_shape, **kw)
+        self.A = MatrixNormalWishart(self.offset + (hidden_dim, hidden_dim + control_dim), batch_shape, pad_X=False,
+                                     mask=A_mask, **kw)
+        self.obs_model = obs_model
+        if obs_model is None:
+            self.obs_model = MatrixNormalWishart(obs_shape + (hidden_dim + regression_dim,), batch_shape, mask=B_mask,
+                                                 pad_X=False, **kw)
+        self.set_latent_parms()
+        self.px = None
+        self.log2pi = torch.tensor(_LOG2PI, **kw)
+
+    # ------------------------------------------------------------------ inputs
+    def reshape_inputs(self, y, u=None, r=None):
+        """vector format, appended ones, optional expansion to the batch (ref :56-83)"""
+        sample_shape = tuple(y.shape[:y.ndim - len(self.obs_shape)])
+        y = y.unsqueeze(-1)
+        one = torch.ones((), device=y.device, dtype=y.dtype)
+        if u is None:
+            u = one.expand(sample_shape + (self.control_dim, 1))
+        else:
+            u = torch.cat((u, u.new_ones(tuple(u.shape[:-1]) + (1,))), -1).unsqueeze(-1)
+        if r is None:
+            r = one.expand(sample_shape + self.obs_shape[:-1] + (self.regression_dim, 1))
+        else:
+            r = torch.cat((r, r.new_ones(tuple(r.shape[:-1]) + (1,))), -1).unsqueeze(-1)
+        if self.expand_to_batch is True:
+            k = len(sample_shape)
+            for i in range(len(self.batch_shape)):
+                y, u, r = y.unsqueeze(k), u.unsqueeze(k), r.unsqueeze(k)
+            y = y.expand(sample_shape + self.batch_shape + self.obs_shape + (1,))
+            u = u.expand(sample_shape + self.batch_shape + (self.control_dim, 1))
+            r = r.expand(sample_shape + self.batch_shape + self.obs_shape[:-1] + (self.regression_dim, 1))
+        for i in range(len(self.offset)):
+            u = u.unsqueeze(-3)
+        return y, u, r
+
+    # ------------------------------------------------------------------ VB loop
+    def update(self, y, u=None, r=None, p=None, iters=1, lr=1.0, verbose=False):
+        L = -torch.tensor(torch.inf, device=self.device, dtype=self.dtype)
+        L_last = L
+        y, u, r = self.reshape_inputs(y, u, r)
+        for i in range(iters):
+            L_last = L
+            self.update_latents(y, u, r)
+            L = self.ELBO().sum()
+            self.ss_update(p=p, lr=lr)
+            self.obs_model.ss_update(self.SE_xr_xr, self.SE_y_xr, self.SE_y_y, self.T, lr)
+            if verbose:
+                print("Percent Change in ELBO %f" % ((L - L_last) / L.abs() * 100))
+        self.ELBO_last = L
+
+    _STATS = ("SE_x0_x0", "SE_x0", "SE_xpu_xpu", "SE_x_xpu", "SE_x_x", "SE_xr_xr", "SE_y_xr", "SE_y_y")
+
+    def ss_update(self, p=None, lr=1.0):
+        """statistics (time already integrated) -> sum over samples -> M-step of x0 and A (ref :104-154)"""
+        if p is not None:
+            for i in range(len(self.offset)):
+                p = p.unsqueeze(-1)
+            self.T = self.T * p
+            self.N = self.N * p
+            p = p.unsqueeze(-1).unsqueeze(-1)
+            for k in self._STATS:
+                setattr(self, k, getattr(self, k) * p)
+        while self.SE_x_x.ndim > self.batch_dim + len(self.offset) + 2:
+            for k in self._STATS + ("T", "N"):
+                setattr(self, k, getattr(self, k).sum(0))
+        for k in ("SE_x0_x0", "SE_xpu_xpu", "SE_x_x", "SE_xr_xr"):
+            v = getattr(self, k)
+            setattr(self, k, 0.5 * (v + _T(v)))
+        self.x0.ss_update(self.SE_x0_x0, self.SE_x0.squeeze(-1), self.N, lr)
+        self.A.ss_update(self.SE_xpu_xpu, self.SE_x_xpu, self.SE_x_x, self.T, lr)
+        self.set_latent_parms()
+
+    def update_latents(self, y, u, r, p=None, lr=1.0):
+        """E-step: smoothed posteriors px, logZ and the time-integrated statistics (ref :156-216)."""
+        if self.px is None:
+            self.px = MultivariateNormal_vector_format(
+                mu=torch.zeros(tuple(y.shape[:-2]) + (self.hidden_dim, 1), device=y.device, dtype=y.dtype))
+        Sigma_t_tp1, Sigma_x0_x0, SE_x0, logZ, logZ_b = self.forward_backward_loop(y, u, r)
+        mu, Sig = self.px.mu, self.px.Sigma
+        SE_x0_x0 = Sigma_x0_x0 + SE_x0 @ _T(SE_x0)
+        SE_x_x = (mu @ _T(mu) + Sig).sum(0)
+        SE_xp_xp = SE_x_x - (mu[-1] @ _T(mu[-1]) + Sig[-1]) + SE_x0_x0
+        SE_x_u = (mu @ _T(u)).sum(0)
+        SE_xp_u = (mu[:-1] @ _T(u[1:])).sum(0) + SE_x0 @ _T(u[0])
+        SE_xp_x = (mu[:-1] @ _T(mu[1:])).sum(0) + Sigma_t_tp1[:-1].sum(0) + SE_x0 @ _T(mu[0]) + Sigma_t_tp1[-1]
+        SE_x_r = (mu @ _T(r)).sum(0)
+        SE_x_y = (mu @ _T(y)).sum(0)
+        SE_u_u = (u @ _T(u)).sum(0)
+        SE_r_r = (r @ _T(r)).sum(0)
+        SE_y_y = (y @ _T(y)).sum(0)
+        SE_y_r = (y @ _T(r)).sum(0)
+
+        sample_shape = tuple(y.shape[1:y.ndim - self.event_dim - self.batch_dim - 1])
+        lead = sample_shape + self.batch_shape
+        SE_y_r = SE_y_r.expand(lead + self.obs_shape + (self.regression_dim,))
+        SE_u_u = SE_u_u.expand(lead + self.offset + (self.control_dim, self.control_dim))
+        SE_r_r = SE_r_r.expand(lead + self.obs_shape[:-1] + (self.regression_dim, self.regression_dim))
+
+        ones = torch.ones(lead + self.offset, device=y.device, dtype=y.dtype)
+        self.T = y.shape[0] * ones
+        self.N = ones
+        self.SE_x_x = SE_x_x
+        self.SE_x0_x0 = SE_x0_x0
+        self.SE_x0 = SE_x0
+        self.SE_y_xr = torch.cat((_T(SE_x_y), SE_y_r), dim=-1)
+        self.SE_y_y = SE_y_y
+        self.SE_xpu_xpu = torch.cat((torch.cat((SE_xp_xp, SE_xp_u), dim=-1),
+                                     torch.cat((_T(SE_xp_u), SE_u_u), dim=-1)), dim=-2)
+        self.SE_x_xpu = torch.cat((_T(SE_xp_x), SE_x_u), dim=-1)
+        xx = SE_x_x.expand(tuple(SE_x_r.shape[:-2]) + tuple(SE_x_x.shape[-2:]))
+        self.SE_xr_xr = torch.cat((torch.cat((xx, SE_x_r), dim=-1), torch.cat((_T(SE_x_r), SE_r_r), dim=-1)), dim=-2)
+        for i in range(len(self.offset)):
+            logZ = logZ.squeeze(-1)
+        self.logZ = logZ.sum(0)
+
+    def KLqprior(self):
+        KL = self.x0.KLqprior() + self.A.KLqprior()
+        for i in range(len(self.offset)):
+            KL = KL.squeeze(-1)
+        return KL + self.obs_model.KLqprior()
+
+    def ELBO(self):
+        logZ = self.logZ
+        while logZ.ndim > self.batch_dim:
+            logZ = logZ.sum(0)
+        return logZ - self.KLqprior()
+
+    # ------------------------------------------------------------------ model pieces
+    def set_latent_parms(self):
+        """expectations of the transition that the filter consumes (ref :230-242)"""
+        h = self.hidden_dim
+        self.invQ = self.A.EinvSigma()
+        ATQA = self.A.EXTinvUX()
+        self.ATQA_x_x = ATQA[..., :h, :h]
+        self.invATQA_x_x, self.logdetATQA_x_x = ops.spd_inv_logdet(self.ATQA_x_x)
+        self.ATQA_x_u = ATQA[..., :h, h:]
+        self.ATQA_u_u = ATQA[..., h:, h:]
+        QA = self.A.EinvUX()
+        self.QA_xp_x = QA[..., :, :h]
+        self.QA_xp_u = QA[..., :, h:]
+
+    def log_likelihood_function(self, Y, R):
+        """natural parameters of the likelihood of x_t (ref :244-266)"""
+        h = self.hidden_dim
+        self.invR = self.obs_model.EinvSigma()
+        BTRB = self.obs_model.EXTinvUX()
+        self.BTRB_xp_xp = BTRB[..., :h, :h]
+        self.BTRB_xp_r = BTRB[..., :h, h:]
+        self.BTRB_r_r = BTRB[..., h:, h:]
+        BTR = self.obs_model.EXTinvU()
+        self.BTR_xp_y = BTR[..., :h, :]
+        self.BTR_r_y = BTR[..., h:, :]
+
+        invSigma_t_t = self.BTRB_xp_xp
+        invSigmamu_t = self.BTR_xp_y @ Y - self.BTRB_xp_r @ R
+        Residual = -0.5 * _T(Y) @ self.invR @ Y - 0.5 * _T(R) @ self.BTRB_r_r @ R + _T(R) @ self.BTR_r_y @ Y
+        Residual = Residual.squeeze(-1).squeeze(-1) + 0.5 * self.obs_model.ElogdetinvSigma() - 0.5 * self.obs_dim * _LOG2PI
+        for i in range(len(self.obs_shape) - 1):
+            invSigma_t_t = invSigma_t_t.sum(-3 - i, True)
+            invSigmamu_t = invSigmamu_t.sum(-3 - i, True)
+            Residual = Residual.sum(-1 - i, True)
+        invSigma_t_t = invSigma_t_t.expand(tuple(invSigmamu_t.shape[:-2]) + (h, h))
+        return invSigma_t_t, invSigmamu_t, Residual
+
+    @staticmethod
+    def _compact(U, keep_last):
+        """drop broadcast (stride-0) leading axes of an expanded input so that products are not materialised"""
+        idx = tuple(slice(0, 1) if (U.stride(i) == 0 and U.shape[i] > 1) else slice(None)
+                    for i in range(U.ndim - keep_last))
+        return U[idx]
+
+    def forward_backward_loop(self, y, u, r):
+        """Filter + smoother for every series in one persistent kernel launch (K9).
+        Returns Sigma_t_tp1, Sigma_x0_x0, mu_x0, logZ, None like the reference (:332-383) and fills self.px."""
+        h = self.hidden_dim
+        T_max = y.shape[0]
+        sample_shape = tuple(y.shape[1:y.ndim - self.event_dim - self.batch_dim - 1])
+        bo_shape = self.batch_shape + self.offset
+        invSigma_like, invSigmamu_like, Residual_like = self.log_likelihood_function(y, r)
+        Uc = self._compact(u, 2)
+        cu1 = (self.QA_xp_u @ Uc).squeeze(-1)
+        cu2 = (self.ATQA_x_u @ Uc).squeeze(-1)
+        cu3 = (_T(Uc) @ self.ATQA_u_u @ Uc).squeeze(-1).squeeze(-1)
+        x0 = self.x0
+        x0_res = -0.5 * x0.EXTinvUX() + 0.5 * x0.ElogdetinvSigma() - 0.5 * h * _LOG2PI
+        out = ops.lds_smoother(T_max, sample_shape, bo_shape, h, self.invQ, self.ATQA_x_x, self.QA_xp_x,
+                               self.A.ElogdetinvSigma(), x0.EinvSigma(), x0.EinvSigmamu(), x0_res,
+                               invSigma_like, invSigmamu_like.squeeze(-1), Residual_like, cu1, cu2, cu3)
+        self.px.invSigma = out["invSigma"]
+        self.px.invSigmamu = out["invSigmamu"].unsqueeze(-1)
+        self.px.Sigma = out["Sigma"]
+        self.px.mu = out["mu"].unsqueeze(-1)
+        self.px.logdetinvSigma = None
+        return out["Sigma_t_tp1"], out["Sigma_x0_x0"], out["mu_x0"].unsqueeze(-1), out["logZ"], None

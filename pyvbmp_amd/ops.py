@@ -224,3 +224,82 @@ def weighted_moments(X, pv, n_sample_dims, mat_batch):
         fn = getattr(lib, "vbmp_weighted_moments_" + L.suffix(dt))
         L.call(fn, "vbmp_weighted_moments", L.ptr(X2), L.ptr(p2), S, Bo, Bi, D, L.ptr(Nk), L.ptr(SEx), L.ptr(SExx), L.stream_ptr(dev))
     return Nk.reshape(mat_batch), SEx.reshape(mat_batch + (D,)), SExx.reshape(mat_batch + (D, D))
+
+
+def _aligned(t):
+    t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone()
+    return t
+
+
+def _norm3(X, T, sample_shape, bo_shape, inner):
+    """Operand broadcastable to (T,)+sample+bo+inner -> (dense tensor, (st_t, st_s, st_b)) with stride 0 on
+    the axis groups (time / sample / batch) it does not depend on."""
+    lead = (T,) + tuple(sample_shape) + tuple(bo_shape)
+    ni = len(inner)
+    if X.ndim < len(lead) + ni:
+        X = X.reshape((1,) * (len(lead) + ni - X.ndim) + tuple(X.shape))
+    ns, nb = len(sample_shape), len(bo_shape)
+    idx, tgt, dep = [], [], []
+    for lo, hi in ((0, 1), (1, 1 + ns), (1 + ns, 1 + ns + nb)):
+        d = any(X.shape[i] != 1 and X.stride(i) != 0 for i in range(lo, hi))
+        dep.append(d)
+        for i in range(lo, hi):
+            idx.append(slice(None) if d else slice(0, 1))
+            tgt.append(lead[i] if d else 1)
+    Xc = X[tuple(idx)].expand(tuple(tgt) + tuple(inner))
+    n_in = _prod(inner)
+    Ss = _prod(sample_shape) if dep[1] else 1
+    Nb = _prod(bo_shape) if dep[2] else 1
+    Xc = _aligned(Xc.reshape(-1))
+    return Xc, (Ss * Nb * n_in if dep[0] else 0, Nb * n_in if dep[1] else 0, n_in if dep[2] else 0)
+
+
+def lds_smoother(T, sample_shape, bo_shape, H, invQ, ATQA_xx, QA_xp_x, A_Elogdet, x0_P, x0_eta, x0_res,
+                 like_P, like_eta, like_res, cu1, cu2, cu3):
+    """K9: one persistent launch of the information filter + smoother.
+    System / prior parameters: bo_shape + (...).  Per-step operands: broadcastable to (T,)+sample+bo+(...).
+    Returns dict of dense outputs shaped (T,)+sample+bo+(...) (and sample+bo+(...) for the x0 terms)."""
+    dev = L.require_device(invQ, like_eta)
+    lib = L.load()
+    if H > L.LDS_MAX_H:
+        raise L.VbmpHipError(f"hidden_dim {H} > {L.LDS_MAX_H}: not covered by the HIP smoother yet")
+    dt = like_eta.dtype
+    suf = L.suffix(dt)
+    sample_shape, bo_shape = tuple(sample_shape), tuple(bo_shape)
+    NB = _prod(bo_shape)
+    S = _prod(sample_shape) * NB
+
+    def per_b(t, inner):
+        return _aligned(t.to(dt).expand(bo_shape + tuple(inner)).reshape((NB,) + tuple(inner)))
+    keep = [per_b(invQ, (H, H)), per_b(ATQA_xx, (H, H)), per_b(QA_xp_x, (H, H)), per_b(A_Elogdet, ()),
+            per_b(x0_P, (H, H)), per_b(x0_eta, (H,)), per_b(x0_res, ())]
+    steps = [_norm3(like_P.to(dt), T, sample_shape, bo_shape, (H, H)), _norm3(like_eta.to(dt), T, sample_shape, bo_shape, (H,)),
+             _norm3(like_res.to(dt), T, sample_shape, bo_shape, ()), _norm3(cu1.to(dt), T, sample_shape, bo_shape, (H,)),
+             _norm3(cu2.to(dt), T, sample_shape, bo_shape, (H,)), _norm3(cu3.to(dt), T, sample_shape, bo_shape, ())]
+    lead = (T,) + sample_shape + bo_shape
+    out = {"invSigma": torch.empty(lead + (H, H), dtype=dt, device=dev),
+           "invSigmamu": torch.empty(lead + (H,), dtype=dt, device=dev),
+           "Sigma": torch.empty(lead + (H, H), dtype=dt, device=dev),
+           "mu": torch.empty(lead + (H,), dtype=dt, device=dev),
+           "Sigma_t_tp1": torch.empty(lead + (H, H), dtype=dt, device=dev),
+           "logZ": torch.empty(lead, dtype=dt, device=dev),
+           "Sigma_x0_x0": torch.empty(lead[1:] + (H, H), dtype=dt, device=dev),
+           "mu_x0": torch.empty(lead[1:] + (H,), dtype=dt, device=dev)}
+    a = L.LDS_ARGS[suf]()
+    a.T, a.S, a.NB, a.H = T, S, NB, H
+    for name, t in zip(("invQ", "ATQA_xx", "QA_xp_x", "A_Elogdet", "x0_P", "x0_eta", "x0_res"), keep):
+        setattr(a, name, t.data_ptr())
+    for (name, pre), (t, st) in zip((("like_P", "lP"), ("like_eta", "le"), ("like_res", "lr"), ("cu1", "c1"),
+                                     ("cu2", "c2"), ("cu3", "c3")), steps):
+        setattr(a, name, t.data_ptr())
+        setattr(a, pre + "_t", st[0])
+        setattr(a, pre + "_s", st[1])
+        setattr(a, pre + "_b", st[2])
+    for name, t in out.items():
+        setattr(a, name, t.data_ptr())
+    if S > 0 and T > 0:
+        fn = getattr(lib, "vbmp_lds_smoother_" + suf)
+        L.call(fn, "vbmp_lds_smoother", ctypes.byref(a), L.stream_ptr(dev))
+    return out

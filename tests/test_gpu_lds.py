@@ -1,0 +1,113 @@
+"""GPU parity of LinearDynamicalSystems (K9 persistent filter/smoother + K1/K2/K2a M-step) against golden
+fixtures captured from the reference (latent_noise='shared'), and against the CPU oracle on a
+Lorenz-like workload (BASELINE config 4 shape at reduced size)."""
+import pytest
+import torch
+
+from tests.helpers import assert_close
+from tests.test_oracle_lds import LDS_CASES, lds_oracle_states, n_iters
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _make(c):
+    from pyvbmp_amd.models import LinearDynamicalSystems
+    h = int(c["hidden"])
+    obs_shape = tuple(int(v) for v in c["obs_shape"])
+    batch = tuple(int(v) for v in c["batch_shape"])
+    m = LinearDynamicalSystems(obs_shape, h, control_dim=int(c["control"]), regression_dim=int(c["regression"]),
+                               latent_noise='shared', batch_shape=batch, device=DEV, dtype=torch.float64)
+    m.x0.mu = c["init_x0_mu"].to(DEV)
+    m.A.mu = c["init_A_mu"].to(DEV)
+    m.obs_model.mu = c["init_obs_mu"].to(DEV)
+    m.set_latent_parms()
+    m.expand_to_batch = len(batch) > 0
+    return m
+
+
+@pytest.mark.parametrize("case", LDS_CASES)
+def test_lds_golden(golden, case):
+    c = golden("lds")[case]
+    m = _make(c)
+    lr = float(c["lr"])
+    dev = lambda k: c[k].to(DEV) if k in c else None  # noqa: E731
+    y, u, r = m.reshape_inputs(dev("y"), dev("u"), dev("r"))
+    tol = 1e-9
+    for it in range(1, n_iters(c) + 1):
+        pre = f"it{it}_"
+        m.update_latents(y, u, r)
+        for f in ("mu", "Sigma", "invSigma", "invSigmamu"):
+            assert_close(getattr(m.px, f), c[pre + "px_" + f], tol, what=pre + f)
+        for f in ("SE_x_x", "SE_x0_x0", "SE_x0", "SE_y_xr", "SE_y_y", "SE_xpu_xpu", "SE_x_xpu", "SE_xr_xr", "T", "N",
+                  "logZ"):
+            assert_close(getattr(m, f), c[pre + f], tol, what=pre + f)
+        assert_close(m.ELBO(), c[pre + "ELBO"], tol, what=pre + "ELBO")
+        m.ss_update(p=None, lr=lr)
+        m.obs_model.ss_update(m.SE_xr_xr, m.SE_y_xr, m.SE_y_y, m.T, lr)
+        assert_close(m.x0.mu, c[pre + "x0_mu"], tol)
+        assert_close(m.x0.invU.invU, c[pre + "x0_invU"], tol)
+        assert_close(m.A.mu, c[pre + "A_mu"], tol)
+        assert_close(m.A.invV, c[pre + "A_invV"], tol)
+        assert_close(m.A.invU.invU, c[pre + "A_invU_invU"], tol)
+        assert_close(m.obs_model.mu, c[pre + "obs_mu"], tol)
+        assert_close(m.obs_model.invU.U, c[pre + "obs_invU_U"], tol)
+        for f in ("invQ", "ATQA_x_x", "invATQA_x_x", "logdetATQA_x_x", "ATQA_x_u", "ATQA_u_u", "QA_xp_x", "QA_xp_u"):
+            assert_close(getattr(m, f), c[pre + f], tol, what=pre + f)
+    assert_close(m.KLqprior(), c["KLqprior"], tol)
+
+
+def lorenz(T, S, gen, dt=0.01, stride=5):
+    """Euler-integrated Lorenz-63 trajectories (our own generator; same kind of data as simulations/Lorenz.py)."""
+    x = torch.randn(S, 3, generator=gen, dtype=torch.float64) * 5 + torch.tensor([0.0, 0.0, 25.0], dtype=torch.float64)
+    out = []
+    for i in range(T * stride):
+        dx = torch.stack((10.0 * (x[:, 1] - x[:, 0]), x[:, 0] * (28.0 - x[:, 2]) - x[:, 1],
+                          x[:, 0] * x[:, 1] - 8.0 / 3.0 * x[:, 2]), -1)
+        x = x + dt * dx
+        if i % stride == 0:
+            out.append(x.clone())
+    d = torch.stack(out)  # (T, S, 3)
+    v = torch.cat((d[1:] - d[:-1], d[-1:] - d[-2:-1]), 0) / dt / 20.0
+    z = torch.cat((d / 10.0, v), -1)
+    return z - z.mean((0, 1), keepdim=True)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-8), (torch.float32, 5e-3)])
+def test_lds_estep_vs_oracle_lorenz(dtype, tol):
+    """config-4 shaped E-step (hidden 6, obs 6) at T=200, 96 series: px.* and logZ against the oracle."""
+    from oracle import lds as olds
+    from oracle import mnw as omnw
+    from oracle import niw as oniw
+    from pyvbmp_amd.models import LinearDynamicalSystems
+    T, S, h = 200, 96, 6
+    g = torch.Generator().manual_seed(4)
+    y = lorenz(T, S, g)
+    m = LinearDynamicalSystems((6,), h, latent_noise='shared', device=DEV, dtype=dtype)
+    x0 = oniw.niw_new((h,), (), mu_init=m.x0.mu.cpu().double())
+    A = omnw.mnw_new((h, h + 1), (), mu_init=m.A.mu.cpu().double())
+    obs = omnw.mnw_new((6, h + 1), (), mu_init=m.obs_model.mu.cpu().double())
+    yy, uu, rr = m.reshape_inputs(y.to(dtype).to(DEV))
+    m.update_latents(yy, uu, rr)
+    yo, uo, ro = olds.reshape_inputs(y, None, None, (6,), 1, 1)
+    sm = olds.smoother(olds.latent_parms(A, h), x0, h, yo, uo, ro, obs, 0)
+    for f in ("mu", "Sigma", "invSigma", "invSigmamu"):
+        assert_close(getattr(m.px, f), sm[f], tol, what=f)
+    st = olds.latent_stats(sm, yo, uo, ro, (6,), 1, 1, (), 0)
+    assert_close(m.logZ, st["logZ"], tol, what="logZ")
+    assert_close(m.SE_x_xpu, st["SE_x_xpu"], tol, what="SE_x_xpu")
+    assert_close(m.SE_xpu_xpu, st["SE_xpu_xpu"], tol, what="SE_xpu_xpu")
+
+
+def test_lds_elbo_increases_full_vb():
+    """a few full VB iterations on Lorenz data run end to end and the ELBO goes up"""
+    from pyvbmp_amd.models import LinearDynamicalSystems
+    g = torch.Generator().manual_seed(1)
+    y = lorenz(120, 64, g).to(DEV)
+    m = LinearDynamicalSystems((6,), 6, latent_noise='shared', device=DEV, dtype=torch.float64)
+    elbos = []
+    for _ in range(6):
+        m.update(y, iters=1, lr=1.0)
+        elbos.append(float(m.ELBO_last))
+    assert all(torch.isfinite(torch.tensor(elbos)))
+    assert elbos[-1] > elbos[1]

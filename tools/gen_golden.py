@@ -633,6 +633,80 @@ def gen_gmm():
 GROUPS = {"wishart": gen_wishart, "niw": gen_niw, "mvn": gen_mvn, "matrix_utils": gen_matrix_utils,
           "mnw": gen_mnw, "gmm": gen_gmm}
 
+
+
+# ---------------------------------------------------------------------- LDS
+def snap_lds_state(b, m, pre):
+    snap_niw(b, m.x0, pre + "x0_")
+    snap_mnw(b, m.A, pre + "A_")
+    snap_mnw(b, m.obs_model, pre + "obs_")
+
+
+def lds_case(b, name, T, S, obs_shape, hidden, batch, gen, control=0, regression=0, iters=2, lr=1.0):
+    import contextlib
+    import io
+
+    import models  # reference
+    b.begin(name)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = models.LinearDynamicalSystems(obs_shape, hidden, control_dim=control, regression_dim=regression,
+                                          latent_noise='shared', batch_shape=batch)
+    b.put("T", T)
+    b.put("S", S)
+    b.put("hidden", hidden)
+    b.put("obs_shape", np.array(obs_shape, dtype=np.int64))
+    b.put("batch_shape", np.array(batch, dtype=np.int64))
+    b.put("control", control)
+    b.put("regression", regression)
+    b.put("lr", lr)
+    snap_lds_state(b, m, "init_")
+    # a smooth latent trajectory observed through a random map
+    nb = len(batch)
+    tt = torch.arange(T, dtype=torch.float64).reshape(T, 1, 1)
+    lat = torch.cat([torch.sin(0.2 * tt * (k + 1) + torch.rand(1, S, 1, generator=gen) * 6) for k in range(hidden)], -1)
+    W = torch.randn(obs_shape + (hidden,), generator=gen)
+    y = (W @ lat.reshape((T, S) + (1,) * (len(obs_shape) - 1) + (hidden, 1))).squeeze(-1)
+    y = y + 0.1 * torch.randn(y.shape, generator=gen)
+    u = torch.randn(T, S, control, generator=gen) if control else None
+    r = torch.randn((T, S) + obs_shape[:-1] + (regression,), generator=gen) if regression else None
+    b.put("y", y)
+    b.put("u", u)
+    b.put("r", r)
+    m.expand_to_batch = nb > 0
+    yy, uu, rr = m.reshape_inputs(y, u, r)
+    for it in range(1, iters + 1):
+        m.update_latents(yy, uu, rr)
+        pre = f"it{it}_"
+        for f in ("mu", "Sigma", "invSigma", "invSigmamu"):
+            b.put(pre + "px_" + f, getattr(m.px, f))
+        for f in ("SE_x_x", "SE_x0_x0", "SE_x0", "SE_y_xr", "SE_y_y", "SE_xpu_xpu", "SE_x_xpu", "SE_xr_xr", "T", "N",
+                  "logZ"):
+            b.put(pre + f, getattr(m, f))
+        b.put(pre + "ELBO", m.ELBO())
+        m.ss_update(p=None, lr=lr)
+        m.obs_model.ss_update(m.SE_xr_xr, m.SE_y_xr, m.SE_y_y, m.T, lr)
+        snap_lds_state(b, m, pre)
+        for f in ("invQ", "ATQA_x_x", "invATQA_x_x", "logdetATQA_x_x", "ATQA_x_u", "ATQA_u_u", "QA_xp_x", "QA_xp_u"):
+            b.put(pre + f, getattr(m, f))
+    b.put("KLqprior", m.KLqprior())
+
+
+def gen_lds():
+    b = Book()
+    gen = torch.Generator().manual_seed(707)
+    torch.manual_seed(17)
+    lds_case(b, "lds_h6_o6", 30, 3, (6,), 6, (), gen, iters=3)
+    lds_case(b, "lds_h6_o6_lr", 25, 4, (6,), 6, (), gen, iters=2, lr=0.6)
+    lds_case(b, "lds_h3_o5_ctrl_reg", 20, 3, (5,), 3, (), gen, control=2, regression=2, iters=2)
+    lds_case(b, "lds_h2_o32", 16, 2, (3, 2), 2, (), gen, iters=2)
+    lds_case(b, "lds_h4_o5_batch2", 18, 3, (5,), 4, (2,), gen, iters=2)
+    lds_case(b, "lds_h8_o4", 12, 2, (4,), 8, (), gen, control=1, iters=2)
+    b.save("lds")
+
+
+GROUPS["lds"] = gen_lds
+
+
 if __name__ == "__main__":
     want = sys.argv[1:] or list(GROUPS)
     for g in want:
