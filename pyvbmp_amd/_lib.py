@@ -71,6 +71,12 @@ def _sig_lds(T):
     return [_c_ptr, _c_ptr]  # const vbmp_lds_args_*: passed byref, stream
 
 
+def _sig_tsum(T):
+    # a, sa_t, sa_s, da, b, sb_t, sb_s, db, M, sM_t, sM_s, Tn, S, out, stream
+    return [_c_ptr, _c_i64, _c_i64, _c_int, _c_ptr, _c_i64, _c_i64, _c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64,
+            _c_ptr, _c_ptr]
+
+
 # symbol -> argtypes builder.  Every symbol declared in include/vbmp_hip.h appears here
 # (tests/test_cabi.py cross-checks the header against this table and against the .so).
 SYMBOLS = {
@@ -81,6 +87,7 @@ SYMBOLS = {
     "vbmp_mixture_estep": _sig_estep,
     "vbmp_weighted_moments": _sig_wmom,
     "vbmp_lds_smoother": _sig_lds,
+    "vbmp_tsum_outer": _sig_tsum,
 }
 DTYPES = {"f64": (torch.float64, ctypes.c_double), "f32": (torch.float32, ctypes.c_float)}
 

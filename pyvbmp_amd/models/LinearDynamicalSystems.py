@@ -137,19 +137,23 @@ class LinearDynamicalSystems():
             self.px = MultivariateNormal_vector_format(
                 mu=torch.zeros(tuple(y.shape[:-2]) + (self.hidden_dim, 1), device=y.device, dtype=y.dtype))
         Sigma_t_tp1, Sigma_x0_x0, SE_x0, logZ, logZ_b = self.forward_backward_loop(y, u, r)
+        # time-integrated statistics: K10 cross-moment reductions (no (T, series, h, h) temporaries)
+        Tn = y.shape[0]
         mu, Sig = self.px.mu, self.px.Sigma
+        mv, yv, uv, rv = mu.squeeze(-1), y.squeeze(-1), u.squeeze(-1), r.squeeze(-1)
+        ts = ops.tsum_outer
         SE_x0_x0 = Sigma_x0_x0 + SE_x0 @ _T(SE_x0)
-        SE_x_x = (mu @ _T(mu) + Sig).sum(0)
+        SE_x_x = ts(mv, mv, M=Sig)
         SE_xp_xp = SE_x_x - (mu[-1] @ _T(mu[-1]) + Sig[-1]) + SE_x0_x0
-        SE_x_u = (mu @ _T(u)).sum(0)
-        SE_xp_u = (mu[:-1] @ _T(u[1:])).sum(0) + SE_x0 @ _T(u[0])
-        SE_xp_x = (mu[:-1] @ _T(mu[1:])).sum(0) + Sigma_t_tp1[:-1].sum(0) + SE_x0 @ _T(mu[0]) + Sigma_t_tp1[-1]
-        SE_x_r = (mu @ _T(r)).sum(0)
-        SE_x_y = (mu @ _T(y)).sum(0)
-        SE_u_u = (u @ _T(u)).sum(0)
-        SE_r_r = (r @ _T(r)).sum(0)
-        SE_y_y = (y @ _T(y)).sum(0)
-        SE_y_r = (y @ _T(r)).sum(0)
+        SE_x_u = ts(mv, uv)
+        SE_xp_u = ts(mv, uv, b_from=1, steps=Tn - 1) + SE_x0 @ _T(u[0])
+        SE_xp_x = ts(mv, mv, M=Sigma_t_tp1, b_from=1, steps=Tn - 1) + SE_x0 @ _T(mu[0]) + Sigma_t_tp1[-1]
+        SE_x_r = ts(mv, rv)
+        SE_x_y = ts(mv, yv)
+        SE_u_u = ts(uv, uv)
+        SE_r_r = ts(rv, rv)
+        SE_y_y = ts(yv, yv)
+        SE_y_r = ts(yv, rv)
 
         sample_shape = tuple(y.shape[1:y.ndim - self.event_dim - self.batch_dim - 1])
         lead = sample_shape + self.batch_shape
@@ -213,9 +217,17 @@ class LinearDynamicalSystems():
         self.BTR_r_y = BTR[..., h:, :]
 
         invSigma_t_t = self.BTRB_xp_xp
-        invSigmamu_t = self.BTR_xp_y @ Y - self.BTRB_xp_r @ R
-        Residual = -0.5 * _T(Y) @ self.invR @ Y - 0.5 * _T(R) @ self.BTRB_r_r @ R + _T(R) @ self.BTR_r_y @ Y
-        Residual = Residual.squeeze(-1).squeeze(-1) + 0.5 * self.obs_model.ElogdetinvSigma() - 0.5 * self.obs_dim * _LOG2PI
+        Rc = self._compact(R, 2)  # the regressor is usually the constant bias column: keep it unexpanded
+        invSigmamu_t = self.BTR_xp_y @ Y - self.BTRB_xp_r @ Rc
+        # -1/2 y' invR y + y' (BTR_r_y' r) + const as ONE quadratic-form launch (K3a) instead of per-(t, series) bmm
+        cst = 0.5 * self.obs_model.ElogdetinvSigma() - 0.5 * self.obs_dim * _LOG2PI
+        lin = (_T(self.BTR_r_y) @ Rc).squeeze(-1)
+        quad_r = -0.5 * (_T(Rc) @ self.BTRB_r_r @ Rc).squeeze(-1).squeeze(-1)
+        if lin.ndim == cst.ndim + 1 and tuple(lin.shape[:-1]) == tuple(cst.shape):
+            Residual = ops.quadform_loglike(Y.squeeze(-1), self.invR, lin, cst) + quad_r
+        else:
+            zero = torch.zeros(tuple(cst.shape) + (self.obs_dim,), device=Y.device, dtype=Y.dtype)
+            Residual = ops.quadform_loglike(Y.squeeze(-1), self.invR, zero, cst) + quad_r + (Y.squeeze(-1) * lin).sum(-1)
         for i in range(len(self.obs_shape) - 1):
             invSigma_t_t = invSigma_t_t.sum(-3 - i, True)
             invSigmamu_t = invSigmamu_t.sum(-3 - i, True)

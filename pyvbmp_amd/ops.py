@@ -303,3 +303,48 @@ def lds_smoother(T, sample_shape, bo_shape, H, invQ, ATQA_xx, QA_xp_x, A_Elogdet
         fn = getattr(lib, "vbmp_lds_smoother_" + suf)
         L.call(fn, "vbmp_lds_smoother", ctypes.byref(a), L.stream_ptr(dev))
     return out
+
+
+def _ts_view(X, T, series_shape, d):
+    """X broadcastable to (T,)+series_shape+(d,) -> (tensor kept alive, data_ptr, st_t, st_s): dense along
+    the axes it depends on, stride 0 elsewhere (time and/or series)."""
+    lead = (T,) + tuple(series_shape)
+    if X.ndim < len(lead) + 1:
+        X = X.reshape((1,) * (len(lead) + 1 - X.ndim) + tuple(X.shape))
+    dep_t = X.shape[0] != 1 and X.stride(0) != 0
+    ns = len(series_shape)
+    dep_s = any(X.shape[i] != 1 and X.stride(i) != 0 for i in range(1, 1 + ns))
+    idx = (slice(None) if dep_t else slice(0, 1),) + tuple(slice(None) if dep_s else slice(0, 1) for _ in range(ns))
+    tgt = ((T,) if dep_t else (1,)) + (tuple(series_shape) if dep_s else (1,) * ns) + (d,)
+    Xc = X[idx].expand(tgt).contiguous()
+    S = _prod(series_shape) if dep_s else 1
+    return Xc, (S * d if dep_t else 0), (d if dep_s else 0)
+
+
+def tsum_outer(a, b, M=None, a_from=0, b_from=0, steps=None, series_shape=None):
+    """K10: out[series,i,j] = sum_t a[t+a_from, series, i] * b[t+b_from, series, j] (+ sum_t M[t, series, i, j]).
+    a: (T,)+series+(da,), b: (T,)+series+(db,) (either may be broadcast along time or series)."""
+    dev = L.require_device(a, b, M)
+    lib = L.load()
+    dt = a.dtype
+    T = max(a.shape[0], b.shape[0])
+    if series_shape is None:
+        series_shape = tuple(torch.broadcast_shapes(a.shape[1:-1], b.shape[1:-1]))
+    da, db = a.shape[-1], b.shape[-1]
+    S = _prod(series_shape)
+    ac, sa_t, sa_s = _ts_view(a, T, series_shape, da)
+    bc, sb_t, sb_s = _ts_view(b.to(dt), T, series_shape, db)
+    if steps is None:
+        steps = T - max(a_from, b_from)
+    esz = ac.element_size()
+    Mc, sM_t, sM_s, mptr = None, 0, 0, 0
+    if M is not None:
+        Mc = M.expand((M.shape[0],) + tuple(series_shape) + (da, db)).contiguous()
+        sM_t, sM_s, mptr = S * da * db, da * db, Mc.data_ptr()
+    out = torch.empty(tuple(series_shape) + (da, db), dtype=dt, device=dev)
+    if out.numel() > 0:
+        fn = getattr(lib, "vbmp_tsum_outer_" + L.suffix(dt))
+        L.call(fn, "vbmp_tsum_outer", ctypes.c_void_p(ac.data_ptr() + a_from * sa_t * esz), sa_t, sa_s, da,
+               ctypes.c_void_p(bc.data_ptr() + b_from * sb_t * esz), sb_t, sb_s, db, ctypes.c_void_p(mptr), sM_t, sM_s,
+               steps, S, L.ptr(out), L.stream_ptr(dev))
+    return out

@@ -74,11 +74,85 @@ def bench_copy(args):
           f"{2 * a.numel() * 8 / ts[len(ts) // 2] / 1e6:.1f} GB/s (read+write)")
 
 
+def _time_call(fn, reps=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        s = _rec()
+        fn()
+        e = _rec()
+        torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def bench_mnw(args):
+    """BASELINE config 3: MatrixNormalWishart forward / backward / update, N=262144 messages, n=p=32, fp32."""
+    from pyvbmp_amd.dists import MultivariateNormal_vector_format as VF
+    from pyvbmp_amd.transforms import MatrixNormalWishart
+    N, n, p = args.N, 32, 32
+    dt = torch.float32
+    g = torch.Generator(device="cuda").manual_seed(0)
+    m = MatrixNormalWishart((n, p), (), device="cuda", dtype=dt)
+    X = torch.randn(4096, p, 1, generator=g, device="cuda", dtype=dt)
+    Y = torch.randn(n, p, generator=g, device="cuda", dtype=dt) @ X + 0.3 * torch.randn(4096, n, 1, generator=g, device="cuda", dtype=dt)
+    m.raw_update(X, Y)
+
+    def spd(d):
+        A = torch.randn(N, d, d + 4, generator=g, device="cuda", dtype=dt)
+        return A @ A.transpose(-2, -1) / (d + 4) + 0.5 * torch.eye(d, device="cuda", dtype=dt)
+    Px, ex = spd(p), torch.randn(N, p, 1, generator=g, device="cuda", dtype=dt)
+    Py, ey = spd(n), torch.randn(N, n, 1, generator=g, device="cuda", dtype=dt)
+    bpm = (p * p + p + n * n + n + 1) * 4
+    t = _time_call(lambda: m.forward(VF(invSigma=Px, invSigmamu=ex)))
+    print(f"mnw.forward  N={N} n=p=32 fp32: {t:.3f} ms -> {N / t * 1e3:.3e} msgs/s, {bpm * N / t / 1e6:.1f} GB/s alg ({bpm * N / t / 1e6 / 80:.1f}% of 8 TB/s)", flush=True)
+    t = _time_call(lambda: m.backward(VF(invSigma=Py, invSigmamu=ey)))
+    print(f"mnw.backward N={N} n=p=32 fp32: {t:.3f} ms -> {N / t * 1e3:.3e} msgs/s, {bpm * N / t / 1e6:.1f} GB/s alg ({bpm * N / t / 1e6 / 80:.1f}% of 8 TB/s)", flush=True)
+    Sx = torch.linalg.inv(Px)
+    mux = Sx @ ex
+    Sy = torch.linalg.inv(Py)
+    muy = Sy @ ey
+    bpu = (p * p + p + n * n + n) * 4
+    t = _time_call(lambda: m.update(VF(mu=mux, Sigma=Sx), VF(mu=muy, Sigma=Sy)))
+    print(f"mnw.update   N={N} n=p=32 fp32: {t:.3f} ms -> {N / t * 1e3:.3e} samples/s, {bpu * N / t / 1e6:.1f} GB/s alg ({bpu * N / t / 1e6 / 80:.1f}% of 8 TB/s)", flush=True)
+    t = _time_call(lambda: m.raw_update(mux, muy))
+    print(f"mnw.raw_update N={N}: {t:.3f} ms -> {N / t * 1e3:.3e} samples/s", flush=True)
+
+
+def bench_lds(args):
+    """BASELINE config 4: LDS E-step, T=1000, 4096 series, hidden 6, obs 6 (Lorenz-like data)."""
+    from pyvbmp_amd.models import LinearDynamicalSystems
+    T, S, h = args.T, args.S, 6
+    for dt in (torch.float64, torch.float32):
+        g = torch.Generator(device="cuda").manual_seed(0)
+        y = torch.randn(T, S, 6, generator=g, device="cuda", dtype=dt).cumsum(0) * 0.05
+        m = LinearDynamicalSystems((6,), h, latent_noise='shared', device="cuda", dtype=dt)
+        yy, uu, rr = m.reshape_inputs(y)
+        t_e = _time_call(lambda: m.update_latents(yy, uu, rr), reps=3, warm=1)
+        ev = []
+        _lib.launch_hooks = (lambda n: ev.append((n, _rec())), lambda n: ev.append((n, _rec())))
+        m.forward_backward_loop(yy, uu, rr)
+        _lib.launch_hooks = None
+        torch.cuda.synchronize()
+        tk = [ev[i][1].elapsed_time(ev[i + 1][1]) for i in range(0, len(ev), 2) if ev[i][0] == "vbmp_lds_smoother"]
+        b = 8 if dt == torch.float64 else 4
+        prac, mini = 1968 // 8 * b, 720 // 8 * b
+        print(f"lds E-step {str(dt)[6:]} T={T} S={S} h=6: update_latents {t_e:.2f} ms; smoother kernel {tk[0]:.2f} ms -> "
+              f"{T * S / tk[0] * 1e3:.3e} (t,series)/s; {prac * T * S / tk[0] / 1e6:.1f} GB/s practical-floor bytes "
+              f"({prac * T * S / tk[0] / 1e6 / 80:.2f}% of 8 TB/s), minimal-I/O {mini * T * S / tk[0] / 1e6:.1f} GB/s", flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="*", default=["niw"])
     ap.add_argument("--B", type=int, default=1_000_000)
     ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--N", type=int, default=262144)
+    ap.add_argument("--T", type=int, default=1000)
+    ap.add_argument("--S", type=int, default=4096)
     args = ap.parse_args()
     for w in args.what:
-        {"niw": bench_niw, "copy": bench_copy}[w](args)
+        {"niw": bench_niw, "copy": bench_copy, "mnw": bench_mnw, "lds": bench_lds}[w](args)
