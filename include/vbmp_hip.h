@@ -156,6 +156,35 @@ int vbmp_tsum_outer_f32(const float* a, int64_t sa_t, int64_t sa_s, int da, cons
                         int db, const float* M, int64_t sM_t, int64_t sM_s, int64_t Tn, int64_t S, float* out,
                         void* stream);
 
+/* K7 / K8 -- fused MatrixNormalWishart messages: forward (transforms/MatrixNormalWishart.py:303-328) and
+ * backward (:352-375 with utils/matrix_utils.py:31-46) are the same "sandwich" computation.  Per message
+ * (sample s < S, expert b < NB), with P a d x d SPD matrix:
+ *     q1 = e1' P^-1 e1                ld1 = logdet P
+ *     A  = P + Add1_b ;  Sm = A^-1 ;  v = Sm e2 ;   q2 = e2' v ;   ld2 = logdet A
+ *     q3 = e3' (P + Add2_b)^-1 e3     ld3 = logdet(P + Add2_b)            (only when Add2 != NULL)
+ *     ovec = M_b v   (m) ;            omat = C_b + sign * M_b Sm M_b^T   (m x m)
+ *     q4 = w' omat^-1 w, ld4 = logdet omat,  w = ovec + cvec_b            (only when cvec != NULL)
+ *   forward : P = P_x, e1 = eta_x, e2 = shifted eta, Add1 = n V, M = E[A], C = invEinvSigma, sign = +1 (d = p, m = n)
+ *             Res = -q1/2 + q2/2 - (ld2 - ld1)/2
+ *   backward: P = P_y, e1 = eta_y, e2 = j_y, Add1 = E[R], Add2 = E[R] - G H^-1 G', e3 = eta_y + G H^-1 j_x,
+ *             M = G' = E[RA]', C = H = E[A'RA], sign = -1, cvec = j_x  (d = n, m = p):  omat = invSigma_x,
+ *             ovec + cvec = invSigmamu_x.
+ * P, e1, e2, e3: element (s,b) at base + s*st_s + b*st_b (strides in elements, 0 = shared).  Add1, Add2 (NB,d,d),
+ * M (NB,m,d), C (NB,m,m), cvec (NB,m) dense.  Outputs dense: ovec (S,NB,m), omat (S,NB,m,m),
+ * scal (S,NB,8) = [q1, ld1, q2, ld2, q3, ld3, q4, ld4].
+ * Needs padded(m) <= padded(d) <= VBMP_MNW_MAX_DIM (padding to 1,2,4,8,16,32), NB <= 65535. */
+#define VBMP_MNW_MAX_DIM 32
+int vbmp_mnw_message_f64(const double* P, int64_t sP_s, int64_t sP_b, const double* e1, int64_t s1_s, int64_t s1_b,
+                         const double* e2, int64_t s2_s, int64_t s2_b, const double* e3, int64_t s3_s, int64_t s3_b,
+                         const double* Add1, const double* Add2, const double* M, const double* C, const double* cvec,
+                         double sign, double* ovec, double* omat, double* scal, int64_t S, int64_t NB, int m, int d,
+                         void* stream);
+int vbmp_mnw_message_f32(const float* P, int64_t sP_s, int64_t sP_b, const float* e1, int64_t s1_s, int64_t s1_b,
+                         const float* e2, int64_t s2_s, int64_t s2_b, const float* e3, int64_t s3_s, int64_t s3_b,
+                         const float* Add1, const float* Add2, const float* M, const float* C, const float* cvec,
+                         float sign, float* ovec, float* omat, float* scal, int64_t S, int64_t NB, int m, int d,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,14 @@ def _sig_tsum(T):
             _c_ptr, _c_ptr]
 
 
+def _sig_mnw_msg(T):
+    # (P, e1, e2, e3 each with 2 strides), Add1, Add2, M, C, cvec, sign, ovec, omat, scal, S, NB, m, d, stream
+    return [_c_ptr, _c_i64, _c_i64] * 4 + [_c_ptr] * 5 + [T] + [_c_ptr] * 3 + [_c_i64, _c_i64, _c_int, _c_int, _c_ptr]
+
+
+MNW_MAX_DIM = 32
+
+
 # symbol -> argtypes builder.  Every symbol declared in include/vbmp_hip.h appears here
 # (tests/test_cabi.py cross-checks the header against this table and against the .so).
 SYMBOLS = {
@@ -88,6 +96,7 @@ SYMBOLS = {
     "vbmp_weighted_moments": _sig_wmom,
     "vbmp_lds_smoother": _sig_lds,
     "vbmp_tsum_outer": _sig_tsum,
+    "vbmp_mnw_message": _sig_mnw_msg,
 }
 DTYPES = {"f64": (torch.float64, ctypes.c_double), "f32": (torch.float32, ctypes.c_float)}
 

@@ -348,3 +348,68 @@ def tsum_outer(a, b, M=None, a_from=0, b_from=0, steps=None, series_shape=None):
                ctypes.c_void_p(bc.data_ptr() + b_from * sb_t * esz), sb_t, sb_s, db, ctypes.c_void_p(mptr), sM_t, sM_s,
                steps, S, L.ptr(out), L.stream_ptr(dev))
     return out
+
+
+def _norm2(X, sample_shape, bshape, inner):
+    """Operand broadcastable to sample+bshape+inner -> (dense tensor, st_s, st_b); stride 0 along the group
+    of axes (samples / experts) it does not depend on."""
+    lead = tuple(sample_shape) + tuple(bshape)
+    ni = len(inner)
+    if X.ndim < len(lead) + ni:
+        X = X.reshape((1,) * (len(lead) + ni - X.ndim) + tuple(X.shape))
+    ns, nb = len(sample_shape), len(bshape)
+    idx, tgt, dep = [], [], []
+    for lo, hi in ((0, ns), (ns, ns + nb)):
+        d = any(X.shape[i] != 1 and X.stride(i) != 0 for i in range(lo, hi))
+        dep.append(d)
+        for i in range(lo, hi):
+            idx.append(slice(None) if d else slice(0, 1))
+            tgt.append(lead[i] if d else 1)
+    Xc = _aligned(X[tuple(idx)].expand(tuple(tgt) + tuple(inner)).reshape(-1))
+    n_in = _prod(inner)
+    Nb = _prod(bshape) if dep[1] else 1
+    return Xc, (Nb * n_in if dep[0] else 0), (n_in if dep[1] else 0)
+
+
+def mnw_message_fusable(m, d):
+    """output dim m, elimination dim d"""
+    n, p = m, d
+    def pad(d):
+        return 1 if d <= 1 else 2 if d <= 2 else 4 if d <= 4 else 8 if d <= 8 else 16 if d <= 16 else 32 if d <= 32 else 64
+    return pad(n) <= pad(p) <= L.MNW_MAX_DIM
+
+
+def mnw_message(P, e1, e2, e3, Add1, Add2, M, C, cvec, sign, bshape):
+    """K7/K8 sandwich kernel (see include/vbmp_hip.h).  P: sample+bshape*+(d,d); e1/e2/e3: sample+bshape*+(d,);
+    Add1/Add2 (bshape,d,d); M (bshape,m,d); C (bshape,m,m); cvec (bshape,m) or None.
+    Returns ovec lead+(m,), omat lead+(m,m), scal lead+(8,) with lead = sample+bshape."""
+    dev = L.require_device(P, e1, e2, Add1, M, C)
+    lib = L.load()
+    dt = P.dtype
+    bshape = tuple(bshape)
+    m, d = M.shape[-2], M.shape[-1]
+    nb = len(bshape)
+    shapes = [P.shape[:-2], e1.shape[:-1], e2.shape[:-1], bshape] + ([e3.shape[:-1]] if e3 is not None else [])
+    lead = tuple(torch.broadcast_shapes(*shapes))
+    sample_shape = lead[:len(lead) - nb]
+    S, NB = _prod(sample_shape), _prod(bshape)
+    Pc, sP_s, sP_b = _norm2(P, sample_shape, bshape, (d, d))
+    e1c, s1_s, s1_b = _norm2(e1.to(dt), sample_shape, bshape, (d,))
+    e2c, s2_s, s2_b = _norm2(e2.to(dt), sample_shape, bshape, (d,))
+    e3c, s3_s, s3_b = (None, 0, 0) if e3 is None else _norm2(e3.to(dt), sample_shape, bshape, (d,))
+    A1 = _aligned(Add1.to(dt).expand(bshape + (d, d)))
+    A2 = None if Add2 is None else _aligned(Add2.to(dt).expand(bshape + (d, d)))
+    Mc = _aligned(M.to(dt).expand(bshape + (m, d)))
+    Cc = _aligned(C.to(dt).expand(bshape + (m, m)))
+    cv = None if cvec is None else _aligned(cvec.to(dt).expand(bshape + (m,)))
+    ovec = torch.empty(lead + (m,), dtype=dt, device=dev)
+    omat = torch.empty(lead + (m, m), dtype=dt, device=dev)
+    scal = torch.empty(lead + (8,), dtype=dt, device=dev)
+    if S > 0 and NB > 0:
+        suf = L.suffix(dt)
+        fn = getattr(lib, "vbmp_mnw_message_" + suf)
+        cT = L.DTYPES[suf][1]
+        L.call(fn, "vbmp_mnw_message", L.ptr(Pc), sP_s, sP_b, L.ptr(e1c), s1_s, s1_b, L.ptr(e2c), s2_s, s2_b, L.ptr(e3c),
+               s3_s, s3_b, L.ptr(A1), L.ptr(A2), L.ptr(Mc), L.ptr(Cc), L.ptr(cv), cT(float(sign)), L.ptr(ovec),
+               L.ptr(omat), L.ptr(scal), S, NB, m, d, L.stream_ptr(dev))
+    return ovec, omat, scal

@@ -298,11 +298,24 @@ class MatrixNormalWishart():
         """Message x -> y for a Gaussian input (ref :303-328): returns (MVN_vf(mu, Sigma), Res)."""
         Px, etax = pX.EinvSigma(), pX.EinvSigmamu()
         nV, M = self.n * self.V, self.mean()
-        Sx, ld_x = ops.spd_inv_logdet(Px)
         if self.pad_X:
             nV11, eta, M1 = nV[..., :-1, :-1], etax - nV[..., :-1, -1:], M[..., :-1]
         else:
             nV11, eta, M1 = nV, etax, M
+        bshape = self.batch_shape + self.event_shape[:-2]
+        per_message = any(Px.shape[i] != 1 and Px.stride(i) != 0 for i in range(Px.ndim - 2 - len(bshape)))
+        if per_message and ops.mnw_message_fusable(self.n, M1.shape[-1]):
+            # one precision per message (BASELINE config 3): everything in ONE fused kernel (K7)
+            mu_y, Sigma_yy, sc = ops.mnw_message(Px, etax.squeeze(-1), eta.squeeze(-1), None, nV11, None, M1,
+                                                 self.invEinvSigma(), None, 1.0, bshape)
+            Res = -0.5 * sc[..., 0] + 0.5 * sc[..., 2] - 0.5 * (sc[..., 3] - sc[..., 1])
+            mu_y = mu_y.unsqueeze(-1)
+            if self.pad_X:
+                mu_y = mu_y + M[..., -1:]
+                Res = Res - 0.5 * nV[..., -1, -1]
+            return MultivariateNormal_vector_format(mu=mu_y, Sigma=Sigma_yy), Res
+        # shared precision: one factorisation per expert, per-message work is GEMV (K1 + GEMMs)
+        Sx, ld_x = ops.spd_inv_logdet(Px)
         S, ld_s = ops.spd_inv_logdet(nV11 + Px)
         mu_y = M1 @ (S @ eta)
         if self.pad_X:
@@ -316,6 +329,30 @@ class MatrixNormalWishart():
 
     def backward(self, pY, Res=0.0):
         """Message y -> x (ref :352-375): returns (MVN_vf(invSigma, invSigmamu), Res)."""
+        Py = pY.EinvSigma()
+        bshape = self.batch_shape + self.event_shape[:-2]
+        per_message = any(Py.shape[i] != 1 and Py.stride(i) != 0 for i in range(Py.ndim - 2 - len(bshape)))
+        px_dim = self.p - 1 if self.pad_X else self.p
+        if per_message and ops.mnw_message_fusable(px_dim, self.n):
+            # one precision per message: the block marginalisation and all four residual terms in ONE kernel (K8)
+            Rm, G, H = self.EinvSigma(), self.EinvUX(), self.EXTinvUX()
+            etay = pY.EinvSigmamu()
+            if self.pad_X:
+                G1, H11 = G[..., :, :-1], H[..., :-1, :-1]
+                jy, jx, J11 = etay + G[..., :, -1:], -H[..., :-1, -1:], H[..., -1, -1]
+            else:
+                G1, H11, jy = G, H, etay
+                jx = torch.zeros(tuple(H.shape[:-1]) + (1,), device=self.device, dtype=self.dtype)
+                J11 = 0.0
+            GHinv = G1 @ ops.spd_inverse(H11)                       # per expert
+            K = Rm - GHinv @ _T(G1)
+            eta_y = jy + GHinv @ jx
+            ovec, Pxx, sc = ops.mnw_message(Py, etay.squeeze(-1), jy.squeeze(-1), eta_y.squeeze(-1), Rm, K, _T(G1), H11,
+                                            jx.squeeze(-1), -1.0, bshape)
+            eta_x = ovec.unsqueeze(-1) + jx
+            R = Res + 0.5 * (-sc[..., 0] + sc[..., 1] + sc[..., 4] - sc[..., 5] + sc[..., 6] - sc[..., 7]) \
+                + 0.5 * self.ElogdetinvSigma() - 0.5 * J11 + 0.5 * px_dim * _LOG2PI
+            return MultivariateNormal_vector_format(invSigma=Pxx, invSigmamu=eta_x, logdetinvSigma=sc[..., 7]), R
         Pxx, eta_x, R = self._marginalise(pY, +1.0, Res)
         pX = MultivariateNormal_vector_format(invSigma=Pxx, invSigmamu=eta_x)
         return pX, R - pX.Res()
