@@ -21,6 +21,49 @@ def _sq(a):
     return a.squeeze(-1).squeeze(-1)
 
 
+# ------------------------------------------------------------------ noise models
+def gamma_new(event_shape, batch_shape, scale, alpha_init, beta_init, dtype=torch.float64):
+    """DiagonalWishart / Gamma prior.  ref dists/DiagonalWishart.py:9-20, dists/Gamma.py:7-24 (nu=2, U=0.5).
+    alpha_init / beta_init are the stored random draws of Gamma.py:20-21."""
+    full = tuple(batch_shape) + tuple(event_shape)
+    a0 = torch.tensor(2.0, dtype=dtype).expand(full)
+    b0 = torch.tensor(scale ** 2 / 0.5, dtype=dtype).expand(full)
+    return {"kind": "gamma", "alpha_0": a0, "beta_0": b0, "alpha": alpha_init, "beta": beta_init,
+            "event_dim": len(event_shape)}
+
+
+def _diag(v):
+    return v.unsqueeze(-1) * torch.eye(v.shape[-1], dtype=v.dtype)
+
+
+def _noise_expect(W):
+    """expectations of the noise precision for either a Wishart or a diagonal-Gamma state"""
+    if W.get("kind") == "gamma":
+        mean, minv = W["alpha"] / W["beta"], W["beta"] / (W["alpha"] - 1)
+        lgm = (W["alpha"].log() - W["beta"].log()).sum(-1)
+        return {"EinvSigma": _diag(mean), "ESigma": _diag(minv), "invEinvSigma": _diag(1.0 / mean),
+                "ElogdetinvSigma": lgm, "logdetEinvSigma": mean.log().sum(-1)}
+    return _niw.wishart_expectations(W)
+
+
+def _noise_update(W, arg, N, lr):
+    if W.get("kind") == "gamma":  # ref transforms/MatrixNormalGamma.py:126, dists/DiagonalWishart.py:32-37, Gamma.py:34-46
+        W = dict(W)
+        d = arg.diagonal(dim1=-2, dim2=-1)
+        W["alpha"] = (W["alpha_0"] + N.unsqueeze(-1) / 2.0) * lr + W["alpha"] * (1 - lr)
+        W["beta"] = (W["beta_0"] + d / 2.0) * lr + W["beta"] * (1 - lr)
+        return W
+    return _niw.wishart_ss_update(W, arg, N, lr=lr, beta=None)
+
+
+def _noise_kl(W, ed):
+    if W.get("kind") == "gamma":  # ref dists/Gamma.py:102-104 (summed over the Gamma's event dims)
+        a, b, a0, b0 = W["alpha"], W["beta"], W["alpha_0"], W["beta_0"]
+        kl = (a - a0) * torch.digamma(a) - torch.lgamma(a) + torch.lgamma(a0) + a0 * (b.log() - b0.log()) + a * (b0 / b - 1)
+        return kl.sum(tuple(range(-(ed - 1), 0)))
+    return _niw.wishart_kl(W, ed)
+
+
 def mnw_new(event_shape, batch_shape=(), mu_init=None, mu_0=0.0, scale=1.0, mask=None, X_mask=None, pad_X=False,
             fixed_precision=False, dtype=torch.float64):
     """ref transforms/MatrixNormalWishart.py:20-70.  mu_init = the stored random draw of :42 (already masked)."""
@@ -73,7 +116,7 @@ def mnw_ss_update(st, SExx, SEyx, SEyy, N, lr=1.0, beta=None):
         mu = T(torch.linalg.solve(invV, T(m0 @ iV0 + SEyx)))
     if mask is not None:  # constrained posterior mean, same mask for the whole batch (:111-120)
         V = inv(invV)
-        U = inv(_niw.wishart_expectations(st["W"])["EinvSigma"])
+        U = inv(_noise_expect(st["W"])["EinvSigma"])
         Astar = V.unsqueeze(-3).unsqueeze(-2) * U.unsqueeze(-2).unsqueeze(-1)
         off = ~mask
         A = Astar[..., off, :, :][..., :, off]
@@ -82,7 +125,7 @@ def mnw_ss_update(st, SExx, SEyx, SEyy, N, lr=1.0, beta=None):
         mu = (mu - U @ gamma @ V) * mask
     if not st["fixed_precision"]:
         arg = SEyy - mu @ invV @ T(mu) + m0 @ iV0 @ T(m0)
-        st["W"] = _niw.wishart_ss_update(st["W"], arg, N, lr=lr, beta=None)
+        st["W"] = _noise_update(st["W"], arg, N, lr)
     invV = lr * invV + (1.0 - lr) * st["invV"]
     st["invV"] = 0.5 * (invV + T(invV))
     st["mu"] = lr * mu + (1.0 - lr) * st["mu"]
@@ -150,9 +193,34 @@ def mnw_moments_dists(st, EX, EXXT, EY, EYYT, p=None):
     return SExx, SEyx, SEyy, N
 
 
+def mng_new(event_shape, batch_shape=(), mu_init=None, alpha_init=None, beta_init=None, scale=1.0, mask=None,
+            X_mask=None, pad_X=False, dtype=torch.float64):
+    """MatrixNormalGamma state: an mnw state whose noise model is the diagonal Gamma one.
+    ref transforms/MatrixNormalGamma.py:21-79 (NB :47: the initial mean is drawn without the prior mean)."""
+    st = mnw_new(event_shape, batch_shape, mu_init=mu_init, scale=scale, mask=mask, X_mask=X_mask, pad_X=pad_X,
+                 dtype=dtype)
+    es = tuple(event_shape)
+    if pad_X:
+        es = es[:-1] + (es[-1] + 1,)
+    st["W"] = gamma_new(es[:-1], batch_shape, scale, alpha_init, beta_init, dtype)
+    return st
+
+
+def mng_forward(st, Px, etax):
+    """natural-parameter forward message of MatrixNormalGamma (no Res).  ref transforms/MatrixNormalGamma.py:315-335"""
+    e = mnw_expectations(st)
+    G, H = e["EinvUX"], e["EXTinvUX"]
+    if st["pad_X"]:
+        Jyx, Jxx, jy, jx = -G[..., :, :-1], H[..., :-1, :-1] + Px, G[..., :, -1:], etax - H[..., :-1, -1:]
+    else:
+        Jyx, Jxx, jy, jx = -G, H + Px, torch.zeros(e["EinvSigma"].shape[:-1] + (1,), dtype=Px.dtype), etax
+    Pyy, nBiD = precision_marginalizer(e["EinvSigma"], Jyx, T(Jyx), Jxx)[0:2]
+    return Pyy, jy + nBiD @ jx
+
+
 def mnw_expectations(st):
     """ref transforms/MatrixNormalWishart.py:400-471"""
-    we = _niw.wishart_expectations(st["W"])
+    we = _noise_expect(st["W"])
     R, mu, V, n, p = we["EinvSigma"], st["mu"], st["V"], st["n"], st["p"]
     return {
         "EinvSigma": R, "ESigma": we["ESigma"], "invEinvSigma": we["invEinvSigma"],
@@ -175,10 +243,15 @@ def mnw_kl(st, event_dim=None):
         kl = kl + n / 2.0 * st["logdetinvV_0"] * st["X_mask"].sum((-1, -2))
     kl = kl + 0.5 * n * (st["invV_0"] * st["V"]).sum((-1, -2))
     d = st["mu"] - st["mu_0"]
-    R = _niw.wishart_expectations(st["W"])["EinvSigma"]
+    R = _noise_expect(st["W"])["EinvSigma"]
     kl = kl + 0.5 * (st["invV_0"] * (T(d) @ R @ d)).sum((-1, -2))
     for _ in range(ed - 2):
         kl = kl.sum(-1)
+    if st["W"].get("kind") == "gamma":  # ref transforms/MatrixNormalGamma.py:216-231 (sums the extra event dims again)
+        kl = kl + _noise_kl(st["W"], ed)
+        for _ in range(ed - 2):
+            kl = kl.sum(-1)
+        return kl
     return kl + _niw.wishart_kl(st["W"], ed)
 
 

@@ -1,7 +1,9 @@
 """Distribution nodes.  As in the reference (dists/__init__.py:1-18) each class is re-exported under
 the name of its submodule, so `import pyvbmp_amd.dists.Wishart as Wishart` yields the class."""
 from .Delta import Delta
+from .DiagonalWishart import DiagonalWishart
 from .Dirichlet import Dirichlet
+from .Gamma import Gamma
 from .Mixture import Mixture
 from .MultivariateNormal import MultivariateNormal
 from .MultivariateNormal_vector_format import MultivariateNormal_vector_format

@@ -8,8 +8,8 @@ E-step: the whole information filter + smoother (the reference's Python loops ov
 persistent HIP launch (K9): series-parallel, time-sequential, h x h state in registers.
 M-step: x0.ss_update (K2), A.ss_update / obs_model.ss_update (MatrixNormalWishart: K1 + K2a).
 
-Only latent_noise='shared' (MatrixNormalWishart transition) is on the accelerated path; the reference's
-default transition (MatrixNormalGamma, diagonal noise) is the first "next" row of SURVEY.md 8(f).
+latent_noise='shared' gives a MatrixNormalWishart transition, anything else the reference's default
+MatrixNormalGamma (diagonal noise); both run on the same kernels.
 """
 import math
 
@@ -19,6 +19,7 @@ from .. import ops
 from .._common import resolve
 from ..dists.MultivariateNormal_vector_format import MultivariateNormal_vector_format
 from ..dists.NormalInverseWishart import NormalInverseWishart
+from ..transforms.MatrixNormalGamma import MatrixNormalGamma
 from ..transforms.MatrixNormalWishart import MatrixNormalWishart
 
 _LOG2PI = math.log(2.0 * math.pi)
@@ -31,9 +32,6 @@ def _T(a):
 class LinearDynamicalSystems():
     def __init__(self, obs_shape, hidden_dim, control_dim=0, regression_dim=0, obs_model=None,
                  latent_noise='independent', batch_shape=(), A_mask=None, B_mask=None, device=None, dtype=None):
-        if latent_noise != 'shared':
-            raise NotImplementedError("latent_noise=%r uses MatrixNormalGamma (diagonal transition noise), which is not "
-                                      "on the accelerated path yet; use latent_noise='shared'" % (latent_noise,))
         self.device, self.dtype = resolve(device, dtype)
         control_dim = control_dim + 1
         regression_dim = regression_dim + 1
@@ -59,8 +57,12 @@ class LinearDynamicalSystems():
         self.offset = (1,) * (len(obs_shape) - 1)
         self.expand_to_batch = False
         self.x0 = NormalInverseWishart(self.offset + (hidden_dim,), batch_shape, **kw)
-        self.A = MatrixNormalWishart(self.offset + (hidden_dim, hidden_dim + control_dim), batch_shape, pad_X=False,
-                                     mask=A_mask, **kw)
+        if latent_noise == 'shared':
+            self.A = MatrixNormalWishart(self.offset + (hidden_dim, hidden_dim + control_dim), batch_shape, pad_X=False,
+                                         mask=A_mask, **kw)
+        else:  # the reference's default: diagonal transition noise
+            self.A = MatrixNormalGamma(self.offset + (hidden_dim, hidden_dim + control_dim), batch_shape, pad_X=False,
+                                       mask=A_mask, **kw)
         self.obs_model = obs_model
         if obs_model is None:
             self.obs_model = MatrixNormalWishart(obs_shape + (hidden_dim + regression_dim,), batch_shape, mask=B_mask,

@@ -65,7 +65,7 @@ class MatrixNormalWishart():
         self.mask = None if mask is None else mask.to(self.device)
         self.X_mask = None if X_mask is None else X_mask.to(self.device)
         self.mu_0 = mu_0
-        self.mu = torch.randn(mu_0.shape, device=self.device, dtype=self.dtype) / math.sqrt(self.p) + mu_0
+        self.mu = self._initial_mean(mu_0)
 
         eye = torch.eye(self.p, device=self.device, dtype=self.dtype)
         self.invV_0 = eye.expand(batch_shape + event_shape[:-2] + (self.p, self.p))
@@ -75,8 +75,7 @@ class MatrixNormalWishart():
         self.logdetinvV = zeros
         self.logdetinvV_0 = zeros
 
-        self.invU = Wishart(event_shape=event_shape[:-2] + (self.n, self.n), batch_shape=batch_shape, scale=scale,
-                            device=self.device, dtype=self.dtype)
+        self.invU = self._make_noise(event_shape, batch_shape, scale)
         self.SEyy = 0.0
         self.SExx = 0.0
         self.SEyx = 0.0
@@ -97,6 +96,17 @@ class MatrixNormalWishart():
             self.mu_0 = self.mu_0 * self.mask
             self.mu = self.mu * self.mask
         self.log2pi = torch.tensor(_LOG2PI, device=self.device, dtype=self.dtype)
+
+    # hooks that the diagonal-noise sibling (MatrixNormalGamma) overrides
+    def _initial_mean(self, mu_0):
+        return torch.randn(mu_0.shape, device=self.device, dtype=self.dtype) / math.sqrt(self.p) + mu_0
+
+    def _make_noise(self, event_shape, batch_shape, scale):
+        return Wishart(event_shape=event_shape[:-2] + (self.n, self.n), batch_shape=batch_shape, scale=scale,
+                       device=self.device, dtype=self.dtype)
+
+    def _update_noise(self, W_arg, N, lr):
+        self.invU.ss_update(W_arg, N, lr=lr, beta=None)
 
     def to_event(self, n):
         if n == 0:
@@ -142,7 +152,7 @@ class MatrixNormalWishart():
 
         if self.fixed_precision is False:
             W_arg = SEyy - mu @ invV @ _T(mu) + self.mu_0 @ self.invV_0 @ _T(self.mu_0)
-            self.invU.ss_update(W_arg, N, lr=lr, beta=None)
+            self._update_noise(W_arg, N, lr)
         invV = lr * invV + (1.0 - lr) * self.invV
         self.invV = 0.5 * (invV + _T(invV))
         self.mu = lr * mu + (1.0 - lr) * self.mu

@@ -1,0 +1,108 @@
+"""GPU parity of MatrixNormalGamma and of LinearDynamicalSystems with the reference's default
+(MatrixNormalGamma) transition, against golden fixtures captured from the reference."""
+import pytest
+import torch
+
+from tests.helpers import assert_close
+from tests.test_oracle_mng import LDSG_CASES, MNG_CASES
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _make(c):
+    from pyvbmp_amd.transforms import MatrixNormalGamma
+    batch = tuple(int(v) for v in c["batch_shape"])
+    mask = c["mask"].to(DEV) if "mask" in c else None
+    m = MatrixNormalGamma((int(c["n"]), int(c["p"])), batch, pad_X=bool(int(c["pad_X"])), mask=mask, device=DEV,
+                          dtype=torch.float64)
+    m.mu = c["init_mu"].to(DEV)
+    m.invU.gamma.alpha = c["init_alpha"].to(DEV)
+    m.invU.gamma.beta = c["init_beta"].to(DEV)
+    return m, batch
+
+
+def _check(m, c, pre, tol=1e-10):
+    for f in ("mu", "invV", "V", "logdetinvV"):
+        assert_close(getattr(m, f), c[pre + f], tol, what=pre + f)
+    assert_close(m.invU.gamma.alpha, c[pre + "alpha"], tol)
+    assert_close(m.invU.gamma.beta, c[pre + "beta"], tol)
+
+
+@pytest.mark.parametrize("case", MNG_CASES)
+def test_mng_golden(golden, case):
+    from pyvbmp_amd.dists import Delta
+    from pyvbmp_amd.dists import MultivariateNormal_vector_format as VF
+    c = golden("mng")[case]
+    m, batch = _make(c)
+    X, Y = c["X"].to(DEV), c["Y"].to(DEV)
+    pr = c["p_resp"].to(DEV) if "p_resp" in c else None
+    N = X.shape[0]
+    Xe = X.expand((N,) + batch + tuple(X.shape[-2:]))
+    m.raw_update(Xe, Y, p=pr, lr=1.0)
+    _check(m, c, "raw1_")
+    m.raw_update(Xe, Y, p=pr, lr=0.5)
+    _check(m, c, "raw2_")
+    for f in ("EinvUX", "EXTinvU", "EXTinvUX", "EXinvVXT", "ElogdetinvU", "ElogdetinvSigma", "EinvSigma", "ESigma",
+              "KLqprior", "mean", "weights", "var"):
+        assert_close(getattr(m, f)(), c["raw2_" + f], what=f)
+    assert_close(m.Elog_like(X, Y), c["Elog_like"], what="Elog_like")
+    P, eta, R = m.Elog_like_X(Y)
+    assert_close(P, c["ELX_invSigma"])
+    assert_close(eta, c["ELX_invSigmamu"])
+    assert_close(R, c["ELX_Res"])
+    pY, R = m.predict(X)
+    assert_close(pY.invSigma, c["predict_invSigma"])
+    assert_close(pY.invSigmamu, c["predict_invSigmamu"])
+    assert_close(R, c["predict_Res"], what="predict Res")
+    pYm = m.forward(VF(invSigma=c["fw_in_invSigma"].to(DEV), invSigmamu=c["fw_in_invSigmamu"].to(DEV)))
+    assert_close(pYm.invSigma, c["fw_invSigma"], what="fw P")
+    assert_close(pYm.invSigmamu, c["fw_invSigmamu"], what="fw eta")
+    pXb, R = m.backward(VF(invSigma=c["bw_in_invSigma"].to(DEV), invSigmamu=c["bw_in_invSigmamu"].to(DEV)))
+    assert_close(pXb.invSigma, c["bw_invSigma"], what="bw P")
+    assert_close(pXb.invSigmamu, c["bw_invSigmamu"], what="bw eta")
+    assert_close(R, c["bw_Res"], what="bw Res")
+    pxd = c["upd_x_mu"].shape[-2]
+    pXu = VF(mu=c["upd_x_mu"].to(DEV).expand((N,) + batch + (pxd, 1)).clone(),
+             Sigma=c["upd_x_Sigma"].to(DEV).expand((N,) + batch + (pxd, pxd)).clone())
+    assert_close(m.Elog_like_given_pX_pY(pXu, Delta(Y)), c["ELpXpY"], what="ELpXpY")
+    m.update(pXu, Delta(Y), p=pr, lr=0.8)
+    _check(m, c, "upd_")
+    assert_close(m.KLqprior(), c["KLqprior_end"], what="KL end")
+
+
+@pytest.mark.parametrize("case", LDSG_CASES)
+def test_lds_default_transition_golden(golden, case):
+    from pyvbmp_amd.models import LinearDynamicalSystems
+    from tests.test_oracle_lds import n_iters
+    c = golden("lds_mng")[case]
+    h = int(c["hidden"])
+    obs_shape = tuple(int(v) for v in c["obs_shape"])
+    batch = tuple(int(v) for v in c["batch_shape"])
+    m = LinearDynamicalSystems(obs_shape, h, control_dim=int(c["control"]), regression_dim=int(c["regression"]),
+                               batch_shape=batch, device=DEV, dtype=torch.float64)  # default latent_noise
+    m.x0.mu = c["init_x0_mu"].to(DEV)
+    m.A.mu = c["init_A_mu"].to(DEV)
+    m.A.invU.gamma.alpha = c["init_A_alpha"].to(DEV)
+    m.A.invU.gamma.beta = c["init_A_beta"].to(DEV)
+    m.obs_model.mu = c["init_obs_mu"].to(DEV)
+    m.set_latent_parms()
+    m.expand_to_batch = len(batch) > 0
+    lr = float(c["lr"])
+    dev = lambda k: c[k].to(DEV) if k in c else None  # noqa: E731
+    y, u, r = m.reshape_inputs(dev("y"), dev("u"), dev("r"))
+    for it in range(1, n_iters(c) + 1):
+        pre = f"it{it}_"
+        m.update_latents(y, u, r)
+        for f in ("mu", "Sigma", "invSigma", "invSigmamu"):
+            assert_close(getattr(m.px, f), c[pre + "px_" + f], 1e-9, what=pre + f)
+        for f in ("SE_x_x", "SE_x0_x0", "SE_x0", "SE_y_xr", "SE_y_y", "SE_xpu_xpu", "SE_x_xpu", "SE_xr_xr", "logZ"):
+            assert_close(getattr(m, f), c[pre + f], 1e-9, what=pre + f)
+        assert_close(m.ELBO(), c[pre + "ELBO"], 1e-9, what=pre + "ELBO")
+        m.ss_update(p=None, lr=lr)
+        m.obs_model.ss_update(m.SE_xr_xr, m.SE_y_xr, m.SE_y_y, m.T, lr)
+        assert_close(m.A.mu, c[pre + "A_mu"], 1e-9)
+        assert_close(m.A.invU.gamma.alpha, c[pre + "A_alpha"], 1e-9)
+        assert_close(m.A.invU.gamma.beta, c[pre + "A_beta"], 1e-9)
+        assert_close(m.obs_model.mu, c[pre + "obs_mu"], 1e-9)
+    assert_close(m.KLqprior(), c["KLqprior"], 1e-9)

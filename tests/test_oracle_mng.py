@@ -1,0 +1,110 @@
+"""Pin the MatrixNormalGamma oracle (diagonal-noise sibling of MNW) and the LDS oracle with the reference's
+DEFAULT transition to golden outputs of the reference.  CPU only."""
+import pytest
+import torch
+
+from oracle import lds as olds
+from oracle import mnw as omnw
+from oracle import niw as oniw
+from tests.helpers import assert_close
+
+MNG_CASES = ["mng_4x3_b5", "mng_4x3_b5_pad", "mng_6x7_nobatch", "mng_mask"]
+LDSG_CASES = ["ldsg_h6_o6", "ldsg_h3_o5_ctrl_reg", "ldsg_h4_o5_batch2"]
+
+
+def mng_state(c):
+    batch = tuple(int(v) for v in c["batch_shape"])
+    st = omnw.mng_new((int(c["n"]), int(c["p"])), batch, mu_init=c["init_mu"], alpha_init=c["init_alpha"],
+                      beta_init=c["init_beta"], pad_X=bool(int(c["pad_X"])), mask=c.get("mask"))
+    return st, batch
+
+
+def check_mng(st, c, pre, tol=1e-10):
+    for f in ("mu", "invV", "V", "logdetinvV"):
+        assert_close(st[f], c[pre + f], tol, what=pre + f)
+    assert_close(st["W"]["alpha"], c[pre + "alpha"], tol)
+    assert_close(st["W"]["beta"], c[pre + "beta"], tol)
+
+
+@pytest.mark.parametrize("case", MNG_CASES)
+def test_mng_oracle_golden(golden, case):
+    c = golden("mng")[case]
+    st, batch = mng_state(c)
+    X, Y, pr = c["X"], c["Y"], c.get("p_resp")
+    N = X.shape[0]
+    Xe = X.expand((N,) + batch + X.shape[-2:])
+    st = omnw.mnw_ss_update(st, *omnw.mnw_moments_data(st, Xe, Y, pr), lr=1.0)
+    check_mng(st, c, "raw1_")
+    st = omnw.mnw_ss_update(st, *omnw.mnw_moments_data(st, Xe, Y, pr), lr=0.5)
+    check_mng(st, c, "raw2_")
+    e = omnw.mnw_expectations(st)
+    for f in ("EinvUX", "EXTinvU", "EXTinvUX", "EXinvVXT", "ElogdetinvU", "ElogdetinvSigma", "EinvSigma", "ESigma",
+              "mean", "weights", "var"):
+        assert_close(e[f], c["raw2_" + f], what=f)
+    assert_close(omnw.mnw_kl(st), c["raw2_KLqprior"], what="KL")
+    assert_close(omnw.mnw_elog_like(st, X, Y), c["Elog_like"])
+    P, eta, R = omnw.mnw_elog_like_X(st, Y)
+    assert_close(P, c["ELX_invSigma"])
+    assert_close(eta, c["ELX_invSigmamu"])
+    assert_close(R, c["ELX_Res"])
+    Pyy, etay = omnw.mng_forward(st, c["fw_in_invSigma"], c["fw_in_invSigmamu"])
+    assert_close(Pyy, c["fw_invSigma"], what="fw P")
+    assert_close(etay, c["fw_invSigmamu"], what="fw eta")
+    P, eta, R = omnw.mnw_backward(st, c["bw_in_invSigma"], c["bw_in_invSigmamu"])
+    assert_close(P, c["bw_invSigma"])
+    assert_close(eta, c["bw_invSigmamu"])
+    assert_close(R, c["bw_Res"], what="bw Res")
+    px = c["upd_x_mu"].shape[-2]
+    EX = c["upd_x_mu"].expand((N,) + batch + (px, 1))
+    EXXT = c["upd_x_Sigma"].expand((N,) + batch + (px, px)) + EX @ EX.transpose(-2, -1)
+    EYYT = Y @ Y.transpose(-2, -1)
+    assert_close(omnw.mnw_elog_like_dists(st, EX, EXXT, Y, EYYT), c["ELpXpY"])
+    st = omnw.mnw_ss_update(st, *omnw.mnw_moments_dists(st, EX, EXXT, Y, EYYT, pr), lr=0.8)
+    check_mng(st, c, "upd_")
+    assert_close(omnw.mnw_kl(st), c["KLqprior_end"])
+
+
+def ldsg_states(c):
+    h = int(c["hidden"])
+    obs_shape = tuple(int(v) for v in c["obs_shape"])
+    batch = tuple(int(v) for v in c["batch_shape"])
+    cd, rd = int(c["control"]) + 1, int(c["regression"]) + 1
+    offset = (1,) * (len(obs_shape) - 1)
+    x0 = oniw.niw_new(offset + (h,), batch, mu_init=c["init_x0_mu"])
+    A = omnw.mng_new(offset + (h, h + cd), batch, mu_init=c["init_A_mu"], alpha_init=c["init_A_alpha"],
+                     beta_init=c["init_A_beta"])
+    obs = omnw.mnw_new(obs_shape + (h + rd,), batch, mu_init=c["init_obs_mu"])
+    return x0, A, obs, h, obs_shape, batch, cd, rd
+
+
+@pytest.mark.parametrize("case", LDSG_CASES)
+def test_lds_default_transition_oracle_golden(golden, case):
+    from tests.test_oracle_lds import n_iters
+    c = golden("lds_mng")[case]
+    x0, A, obs, h, obs_shape, batch, cd, rd = ldsg_states(c)
+    nx = len(obs_shape) - 1
+    lr = float(c["lr"])
+    y, u, r = olds.reshape_inputs(c["y"], c.get("u"), c.get("r"), obs_shape, cd, rd, batch, len(batch) > 0)
+    for it in range(1, n_iters(c) + 1):
+        pre = f"it{it}_"
+        sm = olds.smoother(olds.latent_parms(A, h), x0, h, y, u, r, obs, nx)
+        for f in ("mu", "Sigma", "invSigma", "invSigmamu"):
+            assert_close(sm[f], c[pre + "px_" + f], 1e-9, what=pre + f)
+        st = olds.latent_stats(sm, y, u, r, obs_shape, cd, rd, batch, nx)
+        for f in ("SE_x_x", "SE_x_xpu", "SE_xpu_xpu", "SE_xr_xr", "logZ"):
+            assert_close(st[f], c[pre + f], 1e-9, what=pre + f)
+        lz = st["logZ"]
+        while lz.ndim > len(batch):
+            lz = lz.sum(0)
+        kl = oniw.niw_kl(x0) + omnw.mnw_kl(A)
+        for _ in range(nx):
+            kl = kl.squeeze(-1)
+        assert_close(lz - (kl + omnw.mnw_kl(obs)), c[pre + "ELBO"], 1e-9, what=pre + "ELBO")
+        st = olds.reduce_stats(st, len(batch), nx)
+        x0 = oniw.niw_ss_update(x0, st["SE_x0_x0"], st["SE_x0"].squeeze(-1), st["N"], lr)
+        A = omnw.mnw_ss_update(A, st["SE_xpu_xpu"], st["SE_x_xpu"], st["SE_x_x"], st["T"], lr)
+        obs = omnw.mnw_ss_update(obs, st["SE_xr_xr"], st["SE_y_xr"], st["SE_y_y"], st["T"], lr)
+        assert_close(A["mu"], c[pre + "A_mu"], 1e-9)
+        assert_close(A["W"]["alpha"], c[pre + "A_alpha"], 1e-9)
+        assert_close(A["W"]["beta"], c[pre + "A_beta"], 1e-9)
+        assert_close(obs["mu"], c[pre + "obs_mu"], 1e-9)

@@ -707,6 +707,153 @@ def gen_lds():
 GROUPS["lds"] = gen_lds
 
 
+# ---------------------------------------------------------------------- MatrixNormalGamma
+def snap_mng(b, m, prefix=""):
+    for f in ("mu", "invV", "V", "logdetinvV"):
+        b.put(prefix + f, getattr(m, f))
+    b.put(prefix + "alpha", m.invU.gamma.alpha)
+    b.put(prefix + "beta", m.invU.gamma.beta)
+
+
+def mng_case(b, name, n, p, batch, pad_X, gen, mask=None, N=24):
+    b.begin(name)
+    m = transforms.MatrixNormalGamma(event_shape=(n, p), batch_shape=batch, pad_X=pad_X,
+                                     mask=None if mask is None else mask.clone())
+    b.put("n", n)
+    b.put("p", p)
+    b.put("pad_X", int(pad_X))
+    b.put("batch_shape", np.array(batch, dtype=np.int64))
+    if mask is not None:
+        b.put("mask", mask)
+    snap_mng(b, m, "init_")
+    nb = len(batch)
+    W = torch.randn(batch + (n, p), generator=gen)
+    X = torch.randn((N,) + (1,) * nb + (p, 1), generator=gen)
+    Y = W @ X + 0.3 * torch.randn((N,) + batch + (n, 1), generator=gen)
+    pr = torch.softmax(torch.randn((N,) + batch, generator=gen), -1) if nb else None
+    b.put("X", X)
+    b.put("Y", Y)
+    b.put("p_resp", pr)
+    Xe = X.expand((N,) + batch + (p, 1))
+    m.raw_update(Xe, Y, p=pr, lr=1.0)
+    snap_mng(b, m, "raw1_")
+    m.raw_update(Xe, Y, p=pr, lr=0.5)
+    snap_mng(b, m, "raw2_")
+    for f in ("EinvUX", "EXTinvU", "EXTinvUX", "EXinvVXT", "ElogdetinvU", "ElogdetinvSigma", "EinvSigma", "ESigma",
+              "KLqprior", "mean", "weights", "var"):
+        b.put("raw2_" + f, getattr(m, f)())
+    b.put("Elog_like", m.Elog_like(X, Y))
+    iSx, iSmx, R = m.Elog_like_X(Y)
+    b.put("ELX_invSigma", iSx)
+    b.put("ELX_invSigmamu", iSmx)
+    b.put("ELX_Res", R)
+    pY, R = m.predict(X)
+    b.put("predict_invSigma", pY.invSigma)
+    b.put("predict_invSigmamu", pY.invSigmamu)
+    b.put("predict_Res", R)
+    px_P = rand_spd((N,) + (1,) * nb, p, gen)
+    px_eta = torch.randn((N,) + (1,) * nb + (p, 1), generator=gen)
+    b.put("fw_in_invSigma", px_P)
+    b.put("fw_in_invSigmamu", px_eta)
+    pYm = m.forward(dists.MultivariateNormal_vector_format(invSigma=px_P.clone(), invSigmamu=px_eta.clone()))
+    b.put("fw_invSigma", pYm.invSigma)
+    b.put("fw_invSigmamu", pYm.invSigmamu)
+    py_P = rand_spd((N,) + (1,) * nb, n, gen)
+    py_eta = torch.randn((N,) + (1,) * nb + (n, 1), generator=gen)
+    b.put("bw_in_invSigma", py_P)
+    b.put("bw_in_invSigmamu", py_eta)
+    pXb, Res = m.backward(dists.MultivariateNormal_vector_format(invSigma=py_P.clone(), invSigmamu=py_eta.clone()))
+    b.put("bw_invSigma", pXb.invSigma)
+    b.put("bw_invSigmamu", pXb.invSigmamu)
+    b.put("bw_Res", Res)
+    pd = m.p - (1 if pad_X else 0)
+    ux_Sigma = rand_spd((N,) + (1,) * nb, int(pd), gen)
+    ux_mu = torch.randn((N,) + (1,) * nb + (int(pd), 1), generator=gen)
+    b.put("upd_x_mu", ux_mu)
+    b.put("upd_x_Sigma", ux_Sigma)
+    pXu = dists.MultivariateNormal_vector_format(mu=ux_mu.expand((N,) + batch + ux_mu.shape[-2:]).clone(),
+                                                 Sigma=ux_Sigma.expand((N,) + batch + ux_Sigma.shape[-2:]).clone())
+    b.put("ELpXpY", m.Elog_like_given_pX_pY(pXu, dists.Delta(Y)))
+    m.update(pXu, dists.Delta(Y), p=pr, lr=0.8)
+    snap_mng(b, m, "upd_")
+    b.put("KLqprior_end", m.KLqprior())
+
+
+def gen_mng():
+    b = Book()
+    gen = torch.Generator().manual_seed(808)
+    torch.manual_seed(18)
+    mng_case(b, "mng_4x3_b5", 4, 3, (5,), False, gen)
+    mng_case(b, "mng_4x3_b5_pad", 4, 3, (5,), True, gen)
+    mng_case(b, "mng_6x7_nobatch", 6, 7, (), False, gen)
+    mask = torch.rand(4, 3, generator=gen) > 0.3
+    mask[0, 0] = True
+    mng_case(b, "mng_mask", 4, 3, (5,), False, gen, mask=mask)
+    b.save("mng")
+
+
+def snap_lds_state_mng(b, m, pre):
+    snap_niw(b, m.x0, pre + "x0_")
+    snap_mng(b, m.A, pre + "A_")
+    snap_mnw(b, m.obs_model, pre + "obs_")
+
+
+def lds_mng_case(b, name, T, S, obs_shape, hidden, batch, gen, control=0, regression=0, iters=2, lr=1.0):
+    """LinearDynamicalSystems with the reference's DEFAULT transition (MatrixNormalGamma)."""
+    import contextlib
+    import io
+
+    import models  # reference
+    b.begin(name)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = models.LinearDynamicalSystems(obs_shape, hidden, control_dim=control, regression_dim=regression,
+                                          batch_shape=batch)
+    for k, v in (("T", T), ("S", S), ("hidden", hidden), ("control", control), ("regression", regression), ("lr", lr)):
+        b.put(k, v)
+    b.put("obs_shape", np.array(obs_shape, dtype=np.int64))
+    b.put("batch_shape", np.array(batch, dtype=np.int64))
+    snap_lds_state_mng(b, m, "init_")
+    tt = torch.arange(T, dtype=torch.float64).reshape(T, 1, 1)
+    lat = torch.cat([torch.sin(0.2 * tt * (k + 1) + torch.rand(1, S, 1, generator=gen) * 6) for k in range(hidden)], -1)
+    W = torch.randn(obs_shape + (hidden,), generator=gen)
+    y = (W @ lat.reshape((T, S) + (1,) * (len(obs_shape) - 1) + (hidden, 1))).squeeze(-1)
+    y = y + 0.1 * torch.randn(y.shape, generator=gen)
+    u = torch.randn(T, S, control, generator=gen) if control else None
+    r = torch.randn((T, S) + obs_shape[:-1] + (regression,), generator=gen) if regression else None
+    b.put("y", y)
+    b.put("u", u)
+    b.put("r", r)
+    m.expand_to_batch = len(batch) > 0
+    yy, uu, rr = m.reshape_inputs(y, u, r)
+    for it in range(1, iters + 1):
+        m.update_latents(yy, uu, rr)
+        pre = f"it{it}_"
+        for f in ("mu", "Sigma", "invSigma", "invSigmamu"):
+            b.put(pre + "px_" + f, getattr(m.px, f))
+        for f in ("SE_x_x", "SE_x0_x0", "SE_x0", "SE_y_xr", "SE_y_y", "SE_xpu_xpu", "SE_x_xpu", "SE_xr_xr", "T", "N",
+                  "logZ"):
+            b.put(pre + f, getattr(m, f))
+        b.put(pre + "ELBO", m.ELBO())
+        m.ss_update(p=None, lr=lr)
+        m.obs_model.ss_update(m.SE_xr_xr, m.SE_y_xr, m.SE_y_y, m.T, lr)
+        snap_lds_state_mng(b, m, pre)
+    b.put("KLqprior", m.KLqprior())
+
+
+def gen_lds_mng():
+    b = Book()
+    gen = torch.Generator().manual_seed(909)
+    torch.manual_seed(19)
+    lds_mng_case(b, "ldsg_h6_o6", 24, 3, (6,), 6, (), gen, iters=3)
+    lds_mng_case(b, "ldsg_h3_o5_ctrl_reg", 18, 3, (5,), 3, (), gen, control=2, regression=2, iters=2, lr=0.7)
+    lds_mng_case(b, "ldsg_h4_o5_batch2", 16, 3, (5,), 4, (2,), gen, iters=2)
+    b.save("lds_mng")
+
+
+GROUPS["mng"] = gen_mng
+GROUPS["lds_mng"] = gen_lds_mng
+
+
 if __name__ == "__main__":
     want = sys.argv[1:] or list(GROUPS)
     for g in want:
