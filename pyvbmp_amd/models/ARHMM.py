@@ -1,0 +1,97 @@
+"""Autoregressive HMMs: an HMM whose emission node is a MatrixNormalWishart regression per state (surface of the
+reference's models/ARHMM.py:13-91).  ARHMM_prXRY is the role model of DynamicMarkovBlanketDiscovery: latent input x
+(a Gaussian message), observed regressors r and observed outputs y."""
+import torch
+
+from ..dists.Delta import Delta
+from ..dists.MultivariateNormal_vector_format import MultivariateNormal_vector_format
+from ..transforms.MatrixNormalWishart import MatrixNormalWishart
+from .HMM import HMM
+
+
+def _weight(p, k):
+    return p.reshape(tuple(p.shape) + (1,) * k)
+
+
+class ARHMM(HMM):
+    def __init__(self, dim, n, p, batch_shape=(), pad_X=True, X_mask=None, mask=None, transition_mask=None,
+                 device=None, dtype=None):
+        dist = MatrixNormalWishart(event_shape=(n, p), batch_shape=tuple(batch_shape) + (dim,), pad_X=pad_X, X_mask=X_mask,
+                                   mask=mask, device=device, dtype=dtype)
+        super().__init__(dist, transition_mask=transition_mask)
+
+    def obs_logits(self, XY, t=None):
+        if t is not None:
+            return self.obs_dist.Elog_like(XY[0][t], XY[1][t])
+        return self.obs_dist.Elog_like(XY[0], XY[1])
+
+    def update_obs_parms(self, XY, lr=1.0, beta=None):
+        self.obs_dist.raw_update(XY[0], XY[1], p=self.p, lr=lr, beta=beta)
+
+
+class ARHMM_prXY(HMM):
+    def __init__(self, dim, n, p, batch_shape=(), X_mask=None, mask=None, pad_X=True, transition_mask=None,
+                 device=None, dtype=None):
+        dist = MatrixNormalWishart(event_shape=(n, p), batch_shape=tuple(batch_shape) + (dim,), pad_X=pad_X, X_mask=X_mask,
+                                   mask=mask, device=device, dtype=dtype)
+        super().__init__(dist, transition_mask=transition_mask)
+
+    def obs_logits(self, XY):
+        return self.obs_dist.Elog_like_given_pX_pY(XY[0], XY[1])
+
+    def update_obs_parms(self, XY, lr=1.0, beta=None):
+        self.obs_dist.update(XY[0], XY[1], self.p, lr=lr, beta=beta)
+
+    def Elog_like_X_given_pY(self, pY):
+        px, Res = self.obs_dist.Elog_like_X_given_pY(pY)
+        P, eta = px.invSigma, px.invSigmamu
+        if self.p is not None:
+            P = (P * _weight(self.p, 2)).sum(-3)
+            eta = (eta * _weight(self.p, 2)).sum(-3)
+            Res = (Res * self.p).sum(-1)
+        return P, eta, Res
+
+
+class ARHMM_prXRY(HMM):
+    """x: Gaussian message (vector format), r and y observed."""
+
+    def __init__(self, dim, n, p1, p2, batch_shape=(), mask=None, X_mask=None, transition_mask=None, pad_X=False,
+                 device=None, dtype=None):
+        self.p1 = p1
+        self.p2 = p2
+        dist = MatrixNormalWishart(event_shape=(n, p1 + p2), batch_shape=tuple(batch_shape) + (dim,), pad_X=pad_X,
+                                   X_mask=X_mask, mask=mask, device=device, dtype=dtype)
+        super().__init__(dist, transition_mask=transition_mask)
+
+    def _joint_input(self, XRY):
+        """[x; r] as one Gaussian: covariance block-diag(Sigma_x, 0), mean [mu_x; r] (ref :59-66)"""
+        px, R = XRY[0], XRY[1]
+        Sx = px.ESigma()
+        lead = torch.broadcast_shapes(Sx.shape[:-2], R.shape[:-2])
+        Sigma = torch.zeros(tuple(lead) + (self.p1 + self.p2,) * 2, device=Sx.device, dtype=Sx.dtype)
+        Sigma[..., :self.p1, :self.p1] = Sx
+        mu = torch.cat((px.mean().expand(tuple(lead) + (self.p1, 1)), R.expand(tuple(lead) + (self.p2, 1))), dim=-2)
+        return MultivariateNormal_vector_format(mu=mu, Sigma=Sigma)
+
+    def Elog_like(self, XRY):
+        return (self.obs_logits(XRY) * self.p).sum(-1)
+
+    def obs_logits(self, XRY):
+        return self.obs_dist.Elog_like_given_pX_pY(self._joint_input(XRY), Delta(XRY[2]))
+
+    def update_obs_parms(self, XRY, lr=1.0, beta=None):
+        self.obs_dist.update(self._joint_input(XRY), Delta(XRY[2]), p=self.p, lr=lr, beta=beta)
+
+    def Elog_like_X(self, YR):
+        """likelihood of x as natural parameters, averaged over the role posterior (ref :79-91)"""
+        P_xr, eta_xr, Res = self.obs_dist.Elog_like_X(YR[0])
+        p1, R = self.p1, YR[1]
+        P = P_xr[..., :p1, :p1]
+        eta = eta_xr[..., :p1, :] - P_xr[..., :p1, p1:] @ R
+        Res = Res - 0.5 * (P_xr[..., p1:, p1:] * (R * R.transpose(-2, -1))).sum((-1, -2))
+        Res = Res + (eta_xr[..., p1:, :] * R).sum((-1, -2))
+        if self.p is not None:
+            P = (P * _weight(self.p, 2)).sum(-3)
+            eta = (eta * _weight(self.p, 2)).sum(-3)
+            Res = (Res * self.p).sum(-1)
+        return P, eta, Res

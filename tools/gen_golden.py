@@ -854,6 +854,72 @@ GROUPS["mng"] = gen_mng
 GROUPS["lds_mng"] = gen_lds_mng
 
 
+# ---------------------------------------------------------------------- DMBD
+def snap_dmbd(b, m, pre):
+    snap_niw(b, m.x0, pre + "x0_")
+    snap_mng(b, m.A, pre + "A_")
+    snap_mnw(b, m.B, pre + "B_")
+    b.put(pre + "trans_alpha", m.obs_model.transition.alpha)
+    b.put(pre + "init_alpha", m.obs_model.initial.alpha)
+
+
+def dmbd_case(b, name, T, S, n_obs, obs_dim, role_dims, hidden_dims, gen, number_of_objects=1, iters=3, latent_iters=1):
+    import contextlib
+    import io
+
+    import models  # reference
+    b.begin(name)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = models.DynamicMarkovBlanketDiscovery(obs_shape=(n_obs, obs_dim), role_dims=role_dims, hidden_dims=hidden_dims,
+                                                 batch_shape=(), regression_dim=0, control_dim=0,
+                                                 number_of_objects=number_of_objects)
+    for k, v in (("T", T), ("S", S), ("n_obs", n_obs), ("obs_dim", obs_dim), ("number_of_objects", number_of_objects),
+                 ("latent_iters", latent_iters)):
+        b.put(k, v)
+    b.put("role_dims", np.array(role_dims, dtype=np.int64))
+    b.put("hidden_dims", np.array(hidden_dims, dtype=np.int64))
+    b.put("A_mask", m.A.mask)
+    b.put("B_X_mask", m.B.X_mask)
+    b.put("role_mask", m.obs_model.transition_mask)
+    snap_dmbd(b, m, "init_")
+    b.put("init_B_invU_0", m.B.invU.invU_0)
+    b.put("init_B_logdet_invU_0", m.B.invU.logdet_invU_0)
+    # a few noisy oscillators seen by the observables
+    tt = torch.arange(T, dtype=torch.float64).reshape(T, 1, 1, 1)
+    ph = torch.rand(1, S, n_obs, obs_dim, generator=gen) * 6
+    y = torch.sin(0.25 * tt + ph) + 0.5 * torch.cos(0.11 * tt * (1 + torch.arange(n_obs).reshape(1, 1, n_obs, 1)) + ph)
+    y = y + 0.1 * torch.randn(y.shape, generator=gen)
+    b.put("y", y)
+    for it in range(1, iters + 1):
+        with contextlib.redirect_stdout(io.StringIO()):
+            m.update(y, None, None, iters=1, latent_iters=latent_iters, lr=1.0)
+        pre = f"it{it}_"
+        b.put(pre + "p", m.obs_model.p)
+        b.put(pre + "NA", m.NA)
+        b.put(pre + "SEzz", m.SEzz)
+        b.put(pre + "SEz0", m.SEz0)
+        b.put(pre + "px_mu", m.px.mu)
+        b.put(pre + "px_Sigma", m.px.Sigma)
+        b.put(pre + "logZ", m.logZ)
+        b.put(pre + "ELBO", m.ELBO_last)
+        snap_dmbd(b, m, pre)
+    b.put("assignment_pr", m.assignment_pr())
+    b.put("particular_assignment_pr", m.particular_assignment_pr())
+
+
+def gen_dmbd():
+    b = Book()
+    gen = torch.Generator().manual_seed(1010)
+    torch.manual_seed(20)
+    dmbd_case(b, "dmbd_lorenz_like", 24, 3, 4, 2, (1, 2, 1), (2, 2, 2), gen, iters=3)
+    dmbd_case(b, "dmbd_latent2", 16, 2, 3, 2, (2, 1, 1), (2, 1, 2), gen, iters=2, latent_iters=2)
+    dmbd_case(b, "dmbd_two_objects", 14, 2, 5, 2, (1, 1, 1), (2, 1, 1), gen, number_of_objects=2, iters=2)
+    b.save("dmbd")
+
+
+GROUPS["dmbd"] = gen_dmbd
+
+
 if __name__ == "__main__":
     want = sys.argv[1:] or list(GROUPS)
     for g in want:
