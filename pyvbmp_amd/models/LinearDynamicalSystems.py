@@ -258,12 +258,83 @@ class LinearDynamicalSystems():
         cu3 = (_T(Uc) @ self.ATQA_u_u @ Uc).squeeze(-1).squeeze(-1)
         x0 = self.x0
         x0_res = -0.5 * x0.EXTinvUX() + 0.5 * x0.ElogdetinvSigma() - 0.5 * h * _LOG2PI
-        out = ops.lds_smoother(T_max, sample_shape, bo_shape, h, self.invQ, self.ATQA_x_x, self.QA_xp_x,
-                               self.A.ElogdetinvSigma(), x0.EinvSigma(), x0.EinvSigmamu(), x0_res,
-                               invSigma_like, invSigmamu_like.squeeze(-1), Residual_like, cu1, cu2, cu3)
+        if h <= ops.L.LDS_MAX_H:
+            out = ops.lds_smoother(T_max, sample_shape, bo_shape, h, self.invQ, self.ATQA_x_x, self.QA_xp_x,
+                                   self.A.ElogdetinvSigma(), x0.EinvSigma(), x0.EinvSigmamu(), x0_res,
+                                   invSigma_like, invSigmamu_like.squeeze(-1), Residual_like, cu1, cu2, cu3)
+        else:
+            out = self._smoother_composed(T_max, sample_shape + bo_shape, invSigma_like, invSigmamu_like.squeeze(-1),
+                                          Residual_like, cu1, cu2, cu3, x0_res)
         self.px.invSigma = out["invSigma"]
         self.px.invSigmamu = out["invSigmamu"].unsqueeze(-1)
         self.px.Sigma = out["Sigma"]
         self.px.mu = out["mu"].unsqueeze(-1)
         self.px.logdetinvSigma = None
         return out["Sigma_t_tp1"], out["Sigma_x0_x0"], out["mu_x0"].unsqueeze(-1), out["logZ"], None
+
+    def _smoother_composed(self, T, lead, P_like, eta_like, res_like, cu1, cu2, cu3, x0_res):
+        """Same recursion as K9 for hidden_dim > 8 (e.g. the 52-dimensional flocking DMBD): a host loop over time
+        whose every step is batched over the series -- the inverses / logdets are K1 launches, the products
+        rocBLAS GEMMs.  Launch-bound (about 40 launches per time step); the persistent kernel covers h <= 8."""
+        h = self.hidden_dim
+        kw = {"device": eta_like.device, "dtype": eta_like.dtype}
+        invQ, ATQA, QA = self.invQ, self.ATQA_x_x, self.QA_xp_x
+        QAT = _T(QA)
+        AEl = self.A.ElogdetinvSigma()
+        x0P, x0e = self.x0.EinvSigma(), self.x0.EinvSigmamu()
+
+        def at(X, t, inner):  # time slice of an operand that may not depend on time
+            X = X if X.ndim >= len(lead) + 1 + inner else X.reshape((1,) * (len(lead) + 1 + inner - X.ndim) + tuple(X.shape))
+            return X[t if X.shape[0] > 1 else 0]
+
+        def mv(M, v):
+            return (M @ v.unsqueeze(-1)).squeeze(-1)
+        inv = ops.spd_inv_logdet
+        oP = torch.empty((T,) + lead + (h, h), **kw)
+        oe = torch.empty((T,) + lead + (h,), **kw)
+        oS, om, oC = torch.empty_like(oP), torch.empty_like(oe), torch.empty_like(oP)
+        logZ = torch.empty((T,) + lead, **kw)
+        P = x0P.expand(lead + (h, h))
+        eta = x0e.expand(lead + (h,))
+        res = x0_res.expand(lead)
+        Pi = mu = None
+        for t in range(T):
+            Pl, el, rl = at(P_like, t, 2), at(eta_like, t, 1), at(res_like, t, 0)
+            c1, c2, c3 = at(cu1, t, 1), at(cu2, t, 1), at(cu3, t, 0)
+            S1, ld1 = inv(P + ATQA)
+            em = eta - c2
+            W = QA @ S1
+            P = Pl + invQ - W @ QAT
+            eta = (el + c1) + mv(W, em)
+            res = res + rl - 0.5 * c3 + 0.5 * AEl + 0.5 * (em * mv(S1, em)).sum(-1) - 0.5 * ld1
+            Pi, ld2 = inv(P)
+            mu = mv(Pi, eta)
+            post = -0.5 * (mu * eta).sum(-1) + 0.5 * ld2 - 0.5 * h * _LOG2PI
+            logZ[t] = res - post
+            res = post
+            oP[t], oe[t] = P, eta
+            oC[t - 1] = S1  # t = 0 parks the x0 cross term in the last slot, like the reference
+        oS[T - 1], om[T - 1] = Pi, mu
+        G = torch.zeros(lead + (h, h), **kw)
+        g = torch.zeros(lead + (h,), **kw)
+        for t in range(T - 2, -2, -1):
+            tl, tc = t + 1, (T - 1 if t < 0 else t)
+            Pl, el = at(P_like, tl, 2), at(eta_like, tl, 1)
+            c1, c2 = at(cu1, tl, 1), at(cu2, tl, 1)
+            C0 = oC[tc]
+            Mx = G + Pl + invQ - (QA @ C0) * QAT  # elementwise product as in the reference (:372)
+            oC[tc] = C0 @ QAT @ ops.spd_inverse(Mx)
+            S2 = ops.spd_inverse(invQ + Pl + G)
+            V = QAT @ S2
+            g = mv(V, (c1 + el) + g) - c2
+            G = ATQA - V @ QA
+            if t >= 0:
+                oP[t] = oP[t] + G
+                oe[t] = oe[t] + g
+                oS[t] = ops.spd_inverse(oP[t])
+                om[t] = mv(oS[t], oe[t])
+        S00 = ops.spd_inverse(G + x0P)
+        m0 = mv(S00, g + x0e)
+        return {"invSigma": oP, "invSigmamu": oe, "Sigma": oS, "mu": om, "Sigma_t_tp1": oC, "logZ": logZ,
+                "Sigma_x0_x0": S00, "mu_x0": m0}
+

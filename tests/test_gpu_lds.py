@@ -111,3 +111,32 @@ def test_lds_elbo_increases_full_vb():
         elbos.append(float(m.ELBO_last))
     assert all(torch.isfinite(torch.tensor(elbos)))
     assert elbos[-1] > elbos[1]
+
+
+@pytest.mark.parametrize("case", ["lds_h6_o6", "lds_h3_o5_ctrl_reg", "lds_h4_o5_batch2", "lds_h2_o32"])
+def test_lds_composed_smoother_matches_golden(golden, case, monkeypatch):
+    """the hidden_dim > 8 route (host loop of K1 launches + GEMMs) replayed on the golden cases by forcing it"""
+    from pyvbmp_amd import _lib
+    monkeypatch.setattr(_lib, "LDS_MAX_H", 0)
+    c = golden("lds")[case]
+    m = _make(c)
+    dev = lambda k: c[k].to(DEV) if k in c else None  # noqa: E731
+    y, u, r = m.reshape_inputs(dev("y"), dev("u"), dev("r"))
+    m.update_latents(y, u, r)
+    for f in ("mu", "Sigma", "invSigma", "invSigmamu"):
+        assert_close(getattr(m.px, f), c["it1_px_" + f], 1e-9, what=f)
+    for f in ("SE_x_x", "SE_x0_x0", "SE_x0", "SE_xpu_xpu", "SE_x_xpu", "SE_xr_xr", "logZ"):
+        assert_close(getattr(m, f), c["it1_" + f], 1e-9, what=f)
+
+
+def test_lds_hidden_12_runs():
+    """hidden_dim 12 (> 8): composed route end to end, ELBO finite and increasing"""
+    from pyvbmp_amd.models import LinearDynamicalSystems
+    g = torch.Generator().manual_seed(2)
+    y = lorenz(60, 16, g).to(DEV)
+    m = LinearDynamicalSystems((6,), 12, latent_noise='shared', device=DEV, dtype=torch.float64)
+    e = []
+    for _ in range(4):
+        m.update(y, iters=1)
+        e.append(float(m.ELBO_last))
+    assert all(torch.isfinite(torch.tensor(e))) and e[-1] > e[0]
