@@ -163,14 +163,19 @@ class MatrixNormalWishart():
             self.mu = self.mu * self.X_mask
 
     def _moments(self, EX, EY, covX, covY, p):
-        """SExx, SEyx, SEyy, N (+ bias augmentation) from means / covariances / responsibilities."""
+        """SExx, SEyx, SEyy, N (+ bias augmentation) from means / covariances / responsibilities.
+        Inputs that are shared by all experts (component axes of size 1, e.g. the latent message every role of a
+        DMBD observation sees) are NOT expanded over the experts: the K4 kernel reads each sample once and loops
+        over the experts, and the covariance terms become one GEMM  W^T (S x NB) @ C (S x d^2)."""
         nd = self.event_dim + self.batch_dim
-        sample_shape = tuple(EX.shape[:EX.ndim - nd])
-        nsd = len(sample_shape)
         mat_batch = self.batch_shape + self.event_shape[:-2]
+        nmb = len(mat_batch)
+        lead = tuple(torch.broadcast_shapes(EX.shape[:-2], EY.shape[:-2]))
+        nsd = len(lead) - nmb
+        sample_shape = lead[:nsd]
         full = sample_shape + mat_batch
         px, n = EX.shape[-2], EY.shape[-2]
-        z = torch.cat((EX.expand(full + (px, 1)), EY.expand(full + (n, 1))), dim=-2).squeeze(-1)
+        z = torch.cat((EX.expand(lead + (px, 1)), EY.expand(lead + (n, 1))), dim=-2).squeeze(-1)
         pw = None if p is None else p.reshape(tuple(p.shape) + (1,) * (self.event_dim - 2))
         N, Sz, Szz = ops.weighted_moments(z, pw, nsd, mat_batch)
         SExx, SEyx, SEyy = Szz[..., :px, :px], Szz[..., px:, :px], Szz[..., px:, px:]
@@ -179,13 +184,21 @@ class MatrixNormalWishart():
         def wsum(C):
             if C is None:
                 return 0.0
-            if C.ndim <= len(mat_batch) + 2:  # no sample axes: shared by every sample
+            d = C.shape[-1]
+            if C.ndim <= nmb + 2:  # no sample axes: shared by every sample
                 return C * N.reshape(tuple(N.shape) + (1, 1))
-            C = C.expand(full + tuple(C.shape[-2:]))
+            if C.ndim < len(full) + 2:
+                C = C.reshape((1,) * (len(full) + 2 - C.ndim) + tuple(C.shape))
+            shared = all(C.shape[nsd + i] == 1 for i in range(nmb))
+            S = int(math.prod(sample_shape))
+            if shared and pw is not None and nmb > 0:
+                Cs = C.expand(sample_shape + (1,) * nmb + (d, d)).reshape(S, d * d)
+                W = pw.expand(full).reshape(S, -1)
+                return (W.transpose(0, 1) @ Cs).reshape(mat_batch + (d, d))
+            C = C.expand(full + (d, d))
             if pw is None:
                 return C.sum(tuple(range(nsd)))
-            w = pw.expand(full)
-            return (C * w.reshape(full + (1, 1))).sum(tuple(range(nsd)))
+            return (C * pw.expand(full).reshape(full + (1, 1))).sum(tuple(range(nsd)))
 
         SExx = SExx + wsum(covX)
         SEyy = SEyy + wsum(covY)
@@ -248,10 +261,20 @@ class MatrixNormalWishart():
         ELL = ops.quadform_loglike(self._stack(pX.mean(), pY.mean()), P, b, c)
         px = self.p - 1 if self.pad_X else self.p
         cx, cy = _cov_of(pX), _cov_of(pY)
+        nmb = P.ndim - 2
+
+        def trace_term(C, Pb):
+            """sum_ij C_ij Pb_ij per (sample, expert); one GEMM when C is shared by the experts"""
+            d = C.shape[-1]
+            if nmb > 0 and C.ndim >= nmb + 2 and all(C.shape[C.ndim - 2 - nmb + i] == 1 for i in range(nmb)):
+                lead_s = tuple(C.shape[:C.ndim - 2 - nmb])
+                out = C.reshape(-1, d * d) @ Pb.reshape(-1, d * d).transpose(0, 1)
+                return out.reshape(lead_s + tuple(Pb.shape[:-2]))
+            return (C * Pb).sum((-1, -2))
         if cx is not None:
-            ELL = ELL - 0.5 * (cx * P[..., :px, :px]).sum((-1, -2))
+            ELL = ELL - 0.5 * trace_term(cx, P[..., :px, :px])
         if cy is not None:
-            ELL = ELL - 0.5 * (cy * P[..., px:, px:]).sum((-1, -2))
+            ELL = ELL - 0.5 * trace_term(cy, P[..., px:, px:])
         for i in range(self.event_dim - 2):
             ELL = ELL.sum(-1)
         return ELL
