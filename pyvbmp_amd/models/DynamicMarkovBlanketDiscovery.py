@@ -75,6 +75,8 @@ class DynamicMarkovBlanketDiscovery(LinearDynamicalSystems):
         self.set_latent_parms()
         self.log_like = -torch.tensor(torch.inf, **kw)
         self.log2pi = torch.tensor(_LOG2PI, **kw)
+        self.reducer = None  # SuffStatReducer when the series are sharded over ranks (BASELINE config 5)
+        self._role_entropy = None
 
     # ------------------------------------------------------------------ likelihood of the latents
     def log_likelihood_function(self, Y, R):
@@ -167,8 +169,18 @@ class DynamicMarkovBlanketDiscovery(LinearDynamicalSystems):
                 self.update_assignments(y, r)
                 self.update_latents(y, u, r)
             self.update_assignments(y, r)
-            self.update_obs_parms(y, r, lr=lr)
-            self.update_latents(y, u, r)
+            if self.reducer is not None:
+                # series sharded over ranks: two exchange steps per iteration, each ONE flat all-reduce
+                self._update_obs_parms_sharded(y, r, lr)
+                self.update_latents(y, u, r)
+                om = self.obs_model
+                idx = om.p > 1e-8
+                ent = -(om.p[idx].log() * om.p[idx]).sum()
+                self._role_entropy, = self.reduce_statistics(extra=[ent])
+            else:
+                self._role_entropy = None
+                self.update_obs_parms(y, r, lr=lr)
+                self.update_latents(y, u, r)
             ELBO = self.ELBO()
             self.update_latent_parms(p=None, lr=lr)
             if verbose is True:
@@ -177,13 +189,29 @@ class DynamicMarkovBlanketDiscovery(LinearDynamicalSystems):
             self.ELBO_save = torch.cat((self.ELBO_save, ELBO * torch.ones(1, device=self.device, dtype=self.dtype)), dim=-1)
             self.ELBO_last = ELBO
 
+    def _update_obs_parms_sharded(self, y, r, lr):
+        """update_obs_parms when each rank holds a slice of the series: the Markov statistics of the role chain and
+        the emission moments cross the ranks in one packed all-reduce, then every rank applies the same update"""
+        om, k = self.obs_model, self.obs_model.event_dim + 2
+        XRY = (self._px_for_roles(r).unsqueeze(-k), r.unsqueeze(-k), y.unsqueeze(-k))
+        B = om.obs_dist
+        pXR = om._joint_input(XRY)
+        SExx, SEyx, SEyy, N = B._moments(pXR.EX(), XRY[2], pXR.ESigma(), None, om.p)
+        self.SEzz, self.SEz0, self.NA, SExx, SEyx, SEyy, N = self.reducer.all_reduce(
+            [self.SEzz, self.SEz0, self.NA, SExx, SEyx, SEyy, N])
+        om.update_markov_parms(self.SEzz, self.SEz0, lr)
+        B.ss_update(SExx, SEyx, SEyy, N, lr=lr, beta=None)
+
     def ELBO(self):
         om = self.obs_model
-        idx = om.p > 1e-8
         tl = om.transition.loggeomean()
         ok = tl > -torch.inf
         contrib = (tl[ok] * self.SEzz[ok]).sum() + (om.initial.loggeomean() * self.SEz0).sum()
-        contrib = contrib - (om.p[idx].log() * om.p[idx]).sum()
+        if getattr(self, "_role_entropy", None) is not None:
+            contrib = contrib + self._role_entropy
+        else:
+            idx = om.p > 1e-8
+            contrib = contrib - (om.p[idx].log() * om.p[idx]).sum()
         return super().ELBO() + contrib
 
     # ------------------------------------------------------------------ masks

@@ -70,6 +70,8 @@ class LinearDynamicalSystems():
         self.set_latent_parms()
         self.px = None
         self.log2pi = torch.tensor(_LOG2PI, **kw)
+        # set to a pyvbmp_amd.parallel.SuffStatReducer when the SERIES (sample axis) are sharded over ranks
+        self.reducer = None
 
     # ------------------------------------------------------------------ inputs
     def reshape_inputs(self, y, u=None, r=None):
@@ -104,6 +106,8 @@ class LinearDynamicalSystems():
         for i in range(iters):
             L_last = L
             self.update_latents(y, u, r)
+            if self.reducer is not None:
+                self.reduce_statistics()
             L = self.ELBO().sum()
             self.ss_update(p=p, lr=lr)
             self.obs_model.ss_update(self.SE_xr_xr, self.SE_y_xr, self.SE_y_y, self.T, lr)
@@ -132,6 +136,26 @@ class LinearDynamicalSystems():
         self.x0.ss_update(self.SE_x0_x0, self.SE_x0.squeeze(-1), self.N, lr)
         self.A.ss_update(self.SE_xpu_xpu, self.SE_x_xpu, self.SE_x_x, self.T, lr)
         self.set_latent_parms()
+
+    def reduce_statistics(self, extra=()):
+        """Sample-sharded runs (case 2): sum the local series' statistics, then ONE all-reduce of the
+        flat packed buffer [SE_*, T, N, logZ (+ extra)] over the ranks.  Afterwards ss_update / ELBO see fully reduced
+        tensors (their own sums over the sample axes become no-ops).  Returns the reduced `extra` tensors."""
+        nkeep = self.batch_dim + len(self.offset)
+        names = self._STATS + ("T", "N")
+        local = []
+        for k in names:
+            v = getattr(self, k)
+            extra_dims = v.ndim - nkeep - (0 if k in ("T", "N") else 2)
+            local.append(v.sum(tuple(range(extra_dims))) if extra_dims > 0 else v)
+        lz = self.logZ
+        while lz.ndim > self.batch_dim:
+            lz = lz.sum(0)
+        red = self.reducer.all_reduce(local + [lz] + list(extra))
+        for k, v in zip(names, red):
+            setattr(self, k, v)
+        self.logZ = red[len(names)]
+        return red[len(names) + 1:]
 
     def update_latents(self, y, u, r, p=None, lr=1.0):
         """E-step: smoothed posteriors px, logZ and the time-integrated statistics (ref :156-216)."""

@@ -60,3 +60,100 @@ def test_dmbd_golden(golden, case):
         assert_close(m.x0.mu, c[pre + "x0_mu"], tol)
     assert_close(m.assignment_pr(), c["assignment_pr"], 1e-6)
     assert_close(m.particular_assignment_pr(), c["particular_assignment_pr"], 1e-6)
+
+
+class _PairReducer:
+    """two 'ranks' (threads on one GPU) with a barrier standing in for the all-reduce"""
+
+    def __init__(self):
+        import threading
+        self.bar = threading.Barrier(2)
+        self.slots = [None, None]
+
+    def view(self, rank):
+        outer = self
+
+        class V:
+            calls = 0
+
+            def all_reduce(self, tensors):
+                V.calls += 1
+                outer.slots[rank] = [t.clone() for t in tensors]
+                outer.bar.wait()
+                out = [a + b for a, b in zip(*outer.slots)]
+                outer.bar.wait()
+                return out
+        return V()
+
+
+def _run_pair(make, data_slices, step):
+    import threading
+    shared = _PairReducer()
+    models, errs = [make(), make()], []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            models[rank].reducer = shared.view(rank)
+            step(models[rank], data_slices[rank])
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+            shared.bar.abort()
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    return models
+
+
+def test_lds_series_sharded_matches_single():
+    """LDS with the series split over two ranks: one packed all-reduce per iteration, same posterior as unsharded"""
+    from pyvbmp_amd.models import LinearDynamicalSystems
+    from tests.test_gpu_lds import lorenz
+    g = torch.Generator().manual_seed(3)
+    y = lorenz(80, 24, g).to(DEV)
+    ref = LinearDynamicalSystems((6,), 6, device=DEV, dtype=torch.float64)
+    init = (ref.x0.mu.clone(), ref.A.mu.clone(), ref.A.invU.gamma.alpha.clone(), ref.A.invU.gamma.beta.clone(),
+            ref.obs_model.mu.clone())
+
+    def make():
+        m = LinearDynamicalSystems((6,), 6, device=DEV, dtype=torch.float64)
+        m.x0.mu, m.A.mu, m.A.invU.gamma.alpha, m.A.invU.gamma.beta, m.obs_model.mu = (t.clone() for t in init)
+        m.set_latent_parms()
+        return m
+    ref.update(y, iters=3)
+    models = _run_pair(make, [y[:, :12], y[:, 12:]], lambda m, d: m.update(d, iters=3))
+    for m in models:
+        assert_close(m.A.mu, ref.A.mu, 1e-9)
+        assert_close(m.obs_model.mu, ref.obs_model.mu, 1e-9)
+        assert_close(m.x0.invU.invU, ref.x0.invU.invU, 1e-9)
+        assert_close(m.ELBO_last, ref.ELBO_last, 1e-9)
+
+
+def test_dmbd_series_sharded_matches_single(golden):
+    """BASELINE config 5 logic on one GPU: DMBD with the series split over two ranks (two packed all-reduces per VB
+    iteration) reproduces the unsharded run"""
+    from pyvbmp_amd.models import DynamicMarkovBlanketDiscovery
+    c = golden("dmbd")["dmbd_lorenz_like"]
+    y = torch.cat((c["y"], c["y"].flip(1) * 0.9), 1).to(DEV)  # 6 series
+
+    def make():
+        m = DynamicMarkovBlanketDiscovery(obs_shape=(4, 2), role_dims=(1, 2, 1), hidden_dims=(2, 2, 2), device=DEV,
+                                          dtype=torch.float64)
+        m.A.mu = c["init_A_mu"].to(DEV)
+        m.A.invU.gamma.alpha = c["init_A_alpha"].to(DEV)
+        m.A.invU.gamma.beta = c["init_A_beta"].to(DEV)
+        m.B.mu = c["init_B_mu"].to(DEV)
+        m.obs_model.transition.alpha = c["init_trans_alpha"].to(DEV)
+        m.obs_model.initial.alpha = c["init_init_alpha"].to(DEV)
+        m.set_latent_parms()
+        return m
+    ref = make()
+    ref.update(y, None, None, iters=2)
+    models = _run_pair(make, [y[:, :3], y[:, 3:]], lambda m, d: m.update(d, None, None, iters=2))
+    for m in models:
+        assert m.reducer.calls == 4  # two exchange steps per iteration
+        assert_close(m.A.mu, ref.A.mu, 1e-8)
+        assert_close(m.B.mu, ref.B.mu, 1e-8)
+        assert_close(m.obs_model.transition.alpha, ref.obs_model.transition.alpha, 1e-8)
+        assert_close(m.ELBO_last, ref.ELBO_last, 1e-8)

@@ -145,6 +145,48 @@ def bench_lds(args):
               f"({prac * T * S / tk[0] / 1e6 / 80:.2f}% of 8 TB/s), minimal-I/O {mini * T * S / tk[0] / 1e6:.1f} GB/s", flush=True)
 
 
+def boids(T, S, n, gen, dt=0.1):
+    """small Couzin/boids-style flock in 2-D: (T, S, n, 4) = positions and velocities of n birds (synthetic
+    stand-in for the reference's missing ./data/flocking.pt)"""
+    dev = "cuda"
+    pos = torch.randn(S, n, 2, generator=gen, device=dev, dtype=torch.float64)
+    vel = torch.randn(S, n, 2, generator=gen, device=dev, dtype=torch.float64) * 0.5
+    out = []
+    for _ in range(T):
+        com = pos.mean(1, keepdim=True)
+        d = pos.unsqueeze(2) - pos.unsqueeze(1)                      # (S,n,n,2)
+        rep = (d / (d.pow(2).sum(-1, keepdim=True) + 0.1)).sum(2)
+        align = vel.mean(1, keepdim=True) - vel
+        vel = vel + dt * (0.5 * (com - pos) + 0.3 * rep + 0.4 * align) + 0.05 * torch.randn(vel.shape, generator=gen, device=dev, dtype=torch.float64)
+        vel = vel / vel.norm(dim=-1, keepdim=True).clamp_min(0.3)
+        pos = pos + dt * vel
+        out.append(torch.cat((pos, vel), -1))
+    y = torch.stack(out)
+    return (y - y.mean((0, 1, 2), keepdim=True)) / y.std()
+
+
+def bench_dmbd(args):
+    """BASELINE config 5 (one GPU's share): DMBD with the Flocking_example hyper-parameters (6 objects, hidden 52,
+    25 roles) on synthetic boids data, and with the Lorenz hyper-parameters (hidden 6)."""
+    from pyvbmp_amd.models import DynamicMarkovBlanketDiscovery
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for name, (T, S, n_obs, od, roles, hid, nobj) in {
+            "flocking (hidden 52, 25 roles)": (100, 20, 12, 4, (1, 2, 2), (4, 4, 4), 6),
+            "lorenz-like (hidden 6, 4 roles)": (400, 64, 1, 6, (1, 2, 1), (2, 2, 2), 1)}.items():
+        y = boids(T, S, n_obs, g) if od == 4 else torch.randn(T, S, n_obs, od, generator=g, device="cuda", dtype=torch.float64).cumsum(0) * 0.05
+        m = DynamicMarkovBlanketDiscovery(obs_shape=(n_obs, od), role_dims=roles, hidden_dims=hid, number_of_objects=nobj,
+                                          device="cuda", dtype=torch.float64)
+        m.update(y, None, None, iters=1, lr=0.5)
+        torch.cuda.synchronize()
+        import time
+        t0 = time.perf_counter()
+        its = 3
+        m.update(y, None, None, iters=its, lr=0.5)
+        torch.cuda.synchronize()
+        dt_ = (time.perf_counter() - t0) / its
+        print(f"dmbd {name}: T={T} S={S} n_obs={n_obs}: {dt_ * 1e3:.1f} ms / VB iteration, ELBO {float(m.ELBO_last):.4e}", flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="*", default=["niw"])
@@ -155,4 +197,4 @@ if __name__ == "__main__":
     ap.add_argument("--S", type=int, default=4096)
     args = ap.parse_args()
     for w in args.what:
-        {"niw": bench_niw, "copy": bench_copy, "mnw": bench_mnw, "lds": bench_lds}[w](args)
+        {"niw": bench_niw, "copy": bench_copy, "mnw": bench_mnw, "lds": bench_lds, "dmbd": bench_dmbd}[w](args)
