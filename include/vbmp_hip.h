@@ -185,6 +185,20 @@ int vbmp_mnw_message_f32(const float* P, int64_t sP_s, int64_t sP_b, const float
                          float sign, float* ovec, float* omat, float* scal, int64_t S, int64_t NB, int m, int d,
                          void* stream);
 
+/* K11 -- discrete HMM forward-backward in log space (HMM.forward_backward_logits, models/HMM.py:72-105), the role
+ * chain of DynamicMarkovBlanketDiscovery.  C independent chains of length Tn over K states; chain c uses the
+ * parameters of batch element c % NB.  logits (Tn,C,K): observation log-likelihoods; trans (NB,K,K): E log
+ * transition (row = from, column = to; -inf = forbidden); init (NB,K): E log initial.  Outputs dense:
+ * p (Tn,C,K) = softmax of the smoothed messages with temperature ptemp (:100-101), SEzz (C,K,K) = sum over time of
+ * the pair posteriors incl. the initial step, SEz0 (C,K), logZ (C).  1 <= K <= VBMP_HMM_MAX_K. */
+#define VBMP_HMM_MAX_K 64
+int vbmp_hmm_forward_backward_f64(const double* logits, const double* trans, const double* init, int64_t Tn, int64_t C,
+                                  int64_t NB, int K, double ptemp, double* p, double* SEzz, double* SEz0, double* logZ,
+                                  void* stream);
+int vbmp_hmm_forward_backward_f32(const float* logits, const float* trans, const float* init, int64_t Tn, int64_t C,
+                                  int64_t NB, int K, float ptemp, float* p, float* SEzz, float* SEz0, float* logZ,
+                                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -85,6 +85,14 @@ def _sig_mnw_msg(T):
 MNW_MAX_DIM = 32
 
 
+def _sig_hmm(T):
+    # logits, trans, init, Tn, C, NB, K, ptemp, p, SEzz, SEz0, logZ, stream
+    return [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, T, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr]
+
+
+HMM_MAX_K = 64
+
+
 # symbol -> argtypes builder.  Every symbol declared in include/vbmp_hip.h appears here
 # (tests/test_cabi.py cross-checks the header against this table and against the .so).
 SYMBOLS = {
@@ -97,6 +105,7 @@ SYMBOLS = {
     "vbmp_lds_smoother": _sig_lds,
     "vbmp_tsum_outer": _sig_tsum,
     "vbmp_mnw_message": _sig_mnw_msg,
+    "vbmp_hmm_forward_backward": _sig_hmm,
 }
 DTYPES = {"f64": (torch.float64, ctypes.c_double), "f32": (torch.float32, ctypes.c_float)}
 

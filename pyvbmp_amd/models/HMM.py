@@ -3,11 +3,12 @@ reference's models/HMM.py:5-178).  SURVEY.md 8(f) row 2: the step on either side
 Elog_like_X inside DynamicMarkovBlanketDiscovery.
 
 The log-space forward-backward recursion (:72-105) is sequential in time and tiny per step (K x K
-log-sum-exp per chain); it runs as torch ops on the device, while the observation node's likelihoods and
-updates are the HIP kernels of that node.
+log-sum-exp per chain): it is ONE persistent HIP launch (K11, csrc/k_hmm.hip) with the chains across lane
+groups; the observation node's likelihoods and updates are the HIP kernels of that node.
 """
 import torch
 
+from .. import ops
 from ..dists.Dirichlet import Dirichlet
 
 
@@ -42,6 +43,9 @@ class HMM():
         (time first).  ref models/HMM.py:72-105.  Returns p, SEzz, SEz0, logZ."""
         trans = self.transition.loggeomean()
         init = self.initial.loggeomean()
+        if self.dim <= ops.L.HMM_MAX_K:
+            # ONE persistent launch (K11) instead of two host loops over time
+            return ops.hmm_forward_backward(fw_logits, trans, init, self.batch_shape, self.ptemp)
         T = fw_logits.shape[0]
         fw = [None] * T
         fw[0] = _lse(init.unsqueeze(-1) + trans + fw_logits[0].unsqueeze(-2), -2)

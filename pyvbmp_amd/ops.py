@@ -413,3 +413,29 @@ def mnw_message(P, e1, e2, e3, Add1, Add2, M, C, cvec, sign, bshape):
                s3_s, s3_b, L.ptr(A1), L.ptr(A2), L.ptr(Mc), L.ptr(Cc), L.ptr(cv), cT(float(sign)), L.ptr(ovec),
                L.ptr(omat), L.ptr(scal), S, NB, m, d, L.stream_ptr(dev))
     return ovec, omat, scal
+
+
+def hmm_forward_backward(logits, trans, init, batch_shape, ptemp=1.0):
+    """K11.  logits: (T,)+sample+batch+(K,); trans: batch+(K,K); init: batch+(K,).
+    Returns p (same shape as logits), SEzz sample+batch+(K,K), SEz0 sample+batch+(K,), logZ sample+batch."""
+    dev = L.require_device(logits, trans, init)
+    lib = L.load()
+    dt = logits.dtype
+    K = logits.shape[-1]
+    T = logits.shape[0]
+    lead = tuple(logits.shape[1:-1])
+    C, NB = _prod(lead), _prod(batch_shape)
+    lg = logits.contiguous()
+    tr = trans.to(dt).expand(tuple(batch_shape) + (K, K)).contiguous()
+    ini = init.to(dt).expand(tuple(batch_shape) + (K,)).contiguous()
+    p = torch.empty_like(lg)
+    SEzz = torch.empty(lead + (K, K), dtype=dt, device=dev)
+    SEz0 = torch.empty(lead + (K,), dtype=dt, device=dev)
+    logZ = torch.empty(lead, dtype=dt, device=dev)
+    if C > 0:
+        suf = L.suffix(dt)
+        fn = getattr(lib, "vbmp_hmm_forward_backward_" + suf)
+        cT = L.DTYPES[suf][1]
+        L.call(fn, "vbmp_hmm_forward_backward", L.ptr(lg), L.ptr(tr), L.ptr(ini), T, C, NB, K, cT(float(ptemp)), L.ptr(p),
+               L.ptr(SEzz), L.ptr(SEz0), L.ptr(logZ), L.stream_ptr(dev))
+    return p, SEzz, SEz0, logZ

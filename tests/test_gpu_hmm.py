@@ -1,0 +1,56 @@
+"""GPU parity of the K11 HMM forward-backward kernel against a plain log-space restatement (the algorithm of the
+reference's models/HMM.py:72-105, written here with torch CPU ops) on seeded inputs incl. forbidden transitions."""
+import pytest
+import torch
+
+from tests.helpers import TOL32, assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def hmm_reference(logits, trans, init, ptemp):
+    lse = torch.logsumexp
+    T = logits.shape[0]
+    fw = [None] * T
+    fw[0] = lse(init.unsqueeze(-1) + trans + logits[0].unsqueeze(-2), -2)
+    for t in range(1, T):
+        fw[t] = lse(fw[t - 1].unsqueeze(-1) + trans + logits[t].unsqueeze(-2), -2)
+    logZ = lse(fw[-1], -1, True)
+    fw = [f - logZ for f in fw]
+    SEzz = torch.zeros(fw[0].shape + fw[0].shape[-1:], dtype=logits.dtype)
+    for t in range(T - 2, -1, -1):
+        temp = fw[t].unsqueeze(-1) + trans
+        xi = (temp - lse(temp, -2, True)) + fw[t + 1].unsqueeze(-2)
+        fw[t] = lse(xi, -1)
+        SEzz = SEzz + (xi - lse(xi, (-1, -2), True)).exp()
+    temp = init.unsqueeze(-1) + trans
+    xi = (temp - lse(temp, -2, True)) + fw[0].unsqueeze(-2)
+    z0 = lse(xi, -1)
+    SEz0 = (z0 - lse(z0, -1, True)).exp()
+    SEzz = SEzz + (xi - lse(xi, (-1, -2), True)).exp()
+    p = torch.stack(fw)
+    p = ((p - p.max(-1, keepdim=True)[0]) / ptemp).exp()
+    return p / p.sum(-1, keepdim=True), SEzz, SEz0, logZ.squeeze(-1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("K,T,lead,batch,ptemp", [(4, 30, (5, 3), (), 1.0), (25, 20, (7,), (), 6.0), (3, 17, (4, 2), (2,), 1.0),
+                                                  (2, 9, (1,), (), 1.0), (9, 12, (70,), (), 2.0)])
+def test_hmm_forward_backward_vs_restatement(K, T, lead, batch, ptemp, dtype):
+    from pyvbmp_amd import ops
+    g = torch.Generator().manual_seed(K * 7 + T)
+    logits = (2.0 * torch.randn((T,) + lead + (K,), generator=g, dtype=torch.float64)).to(dtype)
+    A = torch.rand(batch + (K, K), generator=g, dtype=torch.float64) + 0.1
+    mask = torch.rand(K, K, generator=g) > 0.25
+    mask |= torch.eye(K, dtype=torch.bool)
+    trans = torch.where(mask, A.log(), torch.full_like(A, -float("inf")))
+    trans = trans - torch.logsumexp(trans, -1, keepdim=True)
+    init = torch.log_softmax(torch.randn(batch + (K,), generator=g, dtype=torch.float64), -1)
+    p, SEzz, SEz0, logZ = ops.hmm_forward_backward(logits.to(DEV), trans.to(dtype).to(DEV), init.to(dtype).to(DEV), batch, ptemp)
+    rp, rzz, rz0, rlz = hmm_reference(logits.double(), trans, init, ptemp)
+    tol = 1e-10 if dtype == torch.float64 else TOL32 * 5
+    assert_close(p, rp, tol, what="p")
+    assert_close(SEzz, rzz, tol, what="SEzz")
+    assert_close(SEz0, rz0, tol, what="SEz0")
+    assert_close(logZ, rlz, tol, what="logZ")
