@@ -310,7 +310,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 // arithmetic folds to shifts and the 16-byte path is unconditional.
 template <typename T, int Dp, int G, bool FULL>
 __device__ __forceinline__ void tile_g2lds(const T* __restrict__ g, int64_t gstride, int nm, int Drt,
-                                           T* __restrict__ lds, int lane) {
+                                           T* __restrict__ lds, int lane, bool NT = false) {
   using TL = Tile<T, Dp, G>;
   const int D = FULL ? Dp : Drt;
   const int DD = D * D;
@@ -321,9 +321,9 @@ __device__ __forceinline__ void tile_g2lds(const T* __restrict__ g, int64_t gstr
     const typename TL::vec_t* gv = reinterpret_cast<const typename TL::vec_t*>(g);
     // branch-free: a partial last tile re-reads its final chunk and fills LDS slots nobody consumes
     typename TL::vec_t v[NIT];
-    if (nm == TL::MPW) {  // wave-uniform: constant offsets from one base address
+    if (nm == TL::MPW) {  // wave-uniform: constant offsets from one base address; streamed once -> nt
 #pragma unroll
-      for (int i = 0; i < NIT; ++i) v[i] = gv[lane + 64 * i];
+      for (int i = 0; i < NIT; ++i) v[i] = NT ? __builtin_nontemporal_load(&gv[lane + 64 * i]) : gv[lane + 64 * i];
     } else {
 #pragma unroll
       for (int i = 0; i < NIT; ++i) {
@@ -368,7 +368,8 @@ __device__ __forceinline__ void tile_g2lds(const T* __restrict__ g, int64_t gstr
 
 // per-wave LDS image -> global (linear, coalesced)
 template <typename T, int Dp, int G, bool FULL>
-__device__ __forceinline__ void tile_lds2g(T* __restrict__ g, int nm, int Drt, const T* __restrict__ lds, int lane) {
+__device__ __forceinline__ void tile_lds2g(T* __restrict__ g, int nm, int Drt, const T* __restrict__ lds, int lane,
+                                           bool NT = false) {
   using TL = Tile<T, Dp, G>;
   const int D = FULL ? Dp : Drt;
   const int DD = D * D;
@@ -386,10 +387,13 @@ __device__ __forceinline__ void tile_lds2g(T* __restrict__ g, int nm, int Drt, c
       if (c < TL::MPW * Dp * Dp / TL::V)
         v[i] = *reinterpret_cast<const typename TL::vec_t*>(&lds[m * TL::MS + row * TL::RS + cc * TL::V]);
     }
-    if (nm == TL::MPW) {  // wave-uniform: unpredicated stores, constant offsets
+    if (nm == TL::MPW) {  // wave-uniform: unpredicated stores, constant offsets; written once -> nt
 #pragma unroll
       for (int i = 0; i < NIT; ++i)
-        if (lane + 64 * i < TL::MPW * Dp * Dp / TL::V) gv[lane + 64 * i] = v[i];
+        if (lane + 64 * i < TL::MPW * Dp * Dp / TL::V) {
+          if (NT) __builtin_nontemporal_store(v[i], &gv[lane + 64 * i]);
+          else gv[lane + 64 * i] = v[i];
+        }
     } else {
 #pragma unroll
       for (int i = 0; i < NIT; ++i)
