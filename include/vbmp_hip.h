@@ -199,6 +199,12 @@ int vbmp_hmm_forward_backward_f32(const float* logits, const float* trans, const
                                   int64_t NB, int K, float ptemp, float* p, float* SEzz, float* SEz0, float* logZ,
                                   void* stream);
 
+/* K5b -- streaming weighted sum of per-sample matrices: out[e] += sum_{s<S} w[s] * C[s,e], e < E (= d*d): the
+ * covariance part of MatrixNormalWishart.update (sum_s p_s Sigma_s, transforms/MatrixNormalWishart.py:153-155).
+ * C dense (S,E); w (S) or NULL (unit weights); out (E) MUST be zeroed by the caller (atomic accumulation). */
+int vbmp_weighted_matsum_f64(const double* C, const double* w, int64_t S, int64_t E, double* out, void* stream);
+int vbmp_weighted_matsum_f32(const float* C, const float* w, int64_t S, int64_t E, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,6 +93,11 @@ def _sig_hmm(T):
 HMM_MAX_K = 64
 
 
+def _sig_matsum(T):
+    # C, w, S, E, out, stream
+    return [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr]
+
+
 # symbol -> argtypes builder.  Every symbol declared in include/vbmp_hip.h appears here
 # (tests/test_cabi.py cross-checks the header against this table and against the .so).
 SYMBOLS = {
@@ -106,6 +111,7 @@ SYMBOLS = {
     "vbmp_tsum_outer": _sig_tsum,
     "vbmp_mnw_message": _sig_mnw_msg,
     "vbmp_hmm_forward_backward": _sig_hmm,
+    "vbmp_weighted_matsum": _sig_matsum,
 }
 DTYPES = {"f64": (torch.float64, ctypes.c_double), "f32": (torch.float32, ctypes.c_float)}
 

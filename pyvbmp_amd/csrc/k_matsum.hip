@@ -1,0 +1,77 @@
+// K5b: streaming weighted sum of per-sample matrices,  out[e] += sum_s w[s] * C[s, e]   (e < E = d*d),
+// the covariance part of MatrixNormalWishart.update (sum_s p_s Sigma_s, transforms/MatrixNormalWishart.py:153-155).
+// Pure HBM streaming: each block owns a slab of samples, every lane keeps 16 bytes of the row in registers and
+// the rows are read with full-line 16-byte-per-lane loads; partials are combined with float atomics.  gfx950 only.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "vbmp_dispatch.h"
+#include "../../include/vbmp_hip.h"
+
+namespace vbmp {
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_weighted_matsum(const T* __restrict__ C, const T* __restrict__ w, int64_t S,
+                                                         int64_t E, int64_t chunk, T* __restrict__ out) {
+  constexpr int V = 16 / sizeof(T);
+  using vec_t = T __attribute__((ext_vector_type(V)));
+  const int64_t s0 = (int64_t)blockIdx.y * chunk;
+  const int64_t s1 = (s0 + chunk < S) ? s0 + chunk : S;
+  const bool vec_ok = (E % V == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+  if (vec_ok) {
+    const int64_t ev = E / V;
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < ev; c += (int64_t)gridDim.x * 256) {
+      vec_t a0 = {}, a1 = {};
+      const vec_t* base = reinterpret_cast<const vec_t*>(C) + c;
+      int64_t s = s0;
+      for (; s + 2 <= s1; s += 2) {  // two independent chains keep more loads in flight
+        const vec_t v0 = base[s * ev], v1 = base[(s + 1) * ev];
+        const T w0 = w ? w[s] : T(1), w1 = w ? w[s + 1] : T(1);
+        a0 += w0 * v0;
+        a1 += w1 * v1;
+      }
+      if (s < s1) a0 += (w ? w[s] : T(1)) * base[s * ev];
+      a0 += a1;
+#pragma unroll
+      for (int u = 0; u < V; ++u) atomicAdd(&out[c * V + u], a0[u]);
+    }
+  } else {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < E; e += (int64_t)gridDim.x * 256) {
+      T a = T(0);
+      for (int64_t s = s0; s < s1; ++s) a += (w ? w[s] : T(1)) * C[s * E + e];
+      atomicAdd(&out[e], a);
+    }
+  }
+}
+
+template <typename T>
+static int matsum_dispatch(const T* C, const T* w, int64_t S, int64_t E, T* out, void* stream) {
+  if (S == 0 || E == 0) return 0;
+  if (!C || !out || S < 0 || E < 0) return VBMP_ERR_ARG;
+  constexpr int V = 16 / sizeof(T);
+  int64_t bx = (E / V + 255) / 256;
+  if (bx < 1) bx = 1;
+  if (bx > 64) bx = 64;
+  // enough sample slabs to fill the chip (>= 2048 blocks), at least 32 samples each
+  int64_t by = (2048 + bx - 1) / bx;
+  int64_t chunk = (S + by - 1) / by;
+  if (chunk < 32) chunk = 32;
+  by = (S + chunk - 1) / chunk;
+  if (by > 65535) {
+    by = 65535;
+    chunk = (S + by - 1) / by;
+  }
+  hipLaunchKernelGGL((k_weighted_matsum<T>), dim3((unsigned)bx, (unsigned)by), dim3(256), 0, (hipStream_t)stream, C, w, S, E,
+                     chunk, out);
+  return hipGetLastError() == hipSuccess ? 0 : VBMP_ERR_LAUNCH;
+}
+
+}  // namespace vbmp
+
+extern "C" {
+int vbmp_weighted_matsum_f64(const double* C, const double* w, int64_t S, int64_t E, double* out, void* stream) {
+  return vbmp::matsum_dispatch<double>(C, w, S, E, out, stream);
+}
+int vbmp_weighted_matsum_f32(const float* C, const float* w, int64_t S, int64_t E, float* out, void* stream) {
+  return vbmp::matsum_dispatch<float>(C, w, S, E, out, stream);
+}
+}

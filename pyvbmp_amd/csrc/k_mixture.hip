@@ -156,6 +156,102 @@ __global__ __launch_bounds__(256) void k_weighted_moments(const T* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------ K4 on the matrix cores
+// fp32 weighted second moments  SExx[k] = sum_s w[s,k] x_s x_s^T  as an MFMA contraction over the SAMPLE axis
+// (the one place on this path where the contraction is genuinely dense; north star).  D <= 64, Bi == 1, Bo <= 4.
+// v_mfma_f32_32x32x2_f32 consumes two samples per instruction: A[i][k] = w_s x_s[i], B[k][j] = x_s[j] with
+// k = lane>>5 selecting the sample and lane&31 the feature, so every load is two 128-byte row segments.
+// The 64 x 64 result is a 2 x 2 grid of 32 x 32 accumulator tiles per component; sum w x and sum w ride along
+// on the VALU.  Each wave owns a contiguous slab of samples and adds its partial with float atomics
+// (2 x 128-byte segments per atomic instruction: the layout the memory-side atomics run at full rate for).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int NT, int BO>  // NT = feature tiles of 32 (1 or 2), BO = components
+__global__ __launch_bounds__(256) void k_wmom_mfma_f32(const float* __restrict__ X, const float* __restrict__ p,
+                                                        int64_t S, int D, float* __restrict__ Nk,
+                                                        float* __restrict__ SEx, float* __restrict__ SExx) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, f = lane & 31;
+  const int64_t nw = (int64_t)gridDim.x * 4, w = (int64_t)blockIdx.x * 4 + wave;
+  // contiguous slab of sample pairs per wave
+  const int64_t pairs = (S + 1) / 2, per = (pairs + nw - 1) / nw;
+  const int64_t p0 = w * per, p1 = (p0 + per < pairs) ? p0 + per : pairs;
+  f32x16 acc[BO][NT][NT];
+  float sx[BO][NT], sn[BO];
+#pragma unroll
+  for (int k = 0; k < BO; ++k) {
+    sn[k] = 0.f;
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+      sx[k][a] = 0.f;
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][a][b][r] = 0.f;
+    }
+  }
+  for (int64_t pr = p0; pr < p1; ++pr) {
+    const int64_t s = 2 * pr + half;
+    const bool ok = s < S;
+    float x[NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) x[a] = (ok && 32 * a + f < D) ? X[s * D + 32 * a + f] : 0.f;
+#pragma unroll
+    for (int k = 0; k < BO; ++k) {
+      const float wk = ok ? (p ? p[s * BO + k] : 1.f) : 0.f;
+      sn[k] += wk;
+      float wx[NT];
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        wx[a] = wk * x[a];
+        sx[k][a] += wx[a];
+      }
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[k][a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(wx[a], x[b], acc[k][a][b], 0, 0, 0);
+    }
+  }
+  // C layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int k = 0; k < BO; ++k) {
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * half, j = 32 * b + f;
+          if (i < D && j < D) atomicAdd(&SExx[((int64_t)k * D + i) * D + j], acc[k][a][b][r]);
+        }
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+      const float t = sx[k][a] + __shfl_xor(sx[k][a], 32, 64);
+      if (half == 0 && 32 * a + f < D) atomicAdd(&SEx[(int64_t)k * D + 32 * a + f], t);
+    }
+    float tn = sn[k] + __shfl_xor(sn[k], 32, 64);
+    if (lane == 0) atomicAdd(&Nk[k], tn);
+  }
+}
+
+static int wmom_mfma_f32(const float* X, const float* p, int64_t S, int64_t Bo, int D, float* Nk, float* SEx, float* SExx,
+                         hipStream_t st) {
+  int64_t pairs = (S + 1) / 2;
+  int64_t blocks = (pairs + 4 * 64 - 1) / (4 * 64);  // >= 64 sample pairs per wave
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  const dim3 g((unsigned)blocks), b(256);
+#define VBMP_WM(NT, BO) hipLaunchKernelGGL((k_wmom_mfma_f32<NT, BO>), g, b, 0, st, X, p, S, D, Nk, SEx, SExx)
+  const int nt = D <= 32 ? 1 : 2;
+  if (nt == 1) {
+    if (Bo == 1) VBMP_WM(1, 1); else if (Bo == 2) VBMP_WM(1, 2); else if (Bo == 3) VBMP_WM(1, 3); else VBMP_WM(1, 4);
+  } else {
+    if (Bo == 1) VBMP_WM(2, 1); else if (Bo == 2) VBMP_WM(2, 2); else if (Bo == 3) VBMP_WM(2, 3); else VBMP_WM(2, 4);
+  }
+#undef VBMP_WM
+  return hipGetLastError() == hipSuccess ? 0 : VBMP_ERR_LAUNCH;
+}
+
 template <typename T>
 static int quadform_dispatch(const T* X, int64_t S, int64_t Bo, int64_t Bi, int D, const T* P, const T* b, const T* c,
                              T* out, void* stream) {
@@ -193,6 +289,12 @@ static int wmom_dispatch(const T* X, const T* p, int64_t S, int64_t Bo, int64_t 
   if (!X || !Nk || !SEx || !SExx || S < 0 || Bo < 0 || Bi < 0 || D < 1 || D > 2 * VBMP_MAX_DIM || Bi > 65535)
     return VBMP_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
+  if constexpr (sizeof(T) == 4) {
+    // dense contraction over many samples: matrix cores (see k_wmom_mfma_f32)
+    if (Bi == 1 && Bo <= 4 && D <= 64 && S >= 4096)
+      return wmom_mfma_f32(reinterpret_cast<const float*>(X), reinterpret_cast<const float*>(p), S, Bo, D,
+                           reinterpret_cast<float*>(Nk), reinterpret_cast<float*>(SEx), reinterpret_cast<float*>(SExx), st);
+  }
   // samples per block: as many as fit a 48 KiB LDS image of [x | 1 | w] rows (at most 256)
   int CH = (int)((48 * 1024) / ((size_t)(D + 2) * sizeof(T)));
   CH = CH > 256 ? 256 : CH;

@@ -439,3 +439,20 @@ def hmm_forward_backward(logits, trans, init, batch_shape, ptemp=1.0):
         L.call(fn, "vbmp_hmm_forward_backward", L.ptr(lg), L.ptr(tr), L.ptr(ini), T, C, NB, K, cT(float(ptemp)), L.ptr(p),
                L.ptr(SEzz), L.ptr(SEz0), L.ptr(logZ), L.stream_ptr(dev))
     return p, SEzz, SEz0, logZ
+
+
+def weighted_matsum(C, w=None):
+    """K5b: sum_s w[s] * C[s] for C (S, ...) dense and w (S,) or None; returns C.shape[1:]."""
+    dev = L.require_device(C, w)
+    lib = L.load()
+    dt = C.dtype
+    Cc = _aligned(C)
+    S = Cc.shape[0]
+    inner = tuple(Cc.shape[1:])
+    E = _prod(inner)
+    wc = None if w is None else w.to(dt).contiguous()
+    out = torch.zeros(E, dtype=dt, device=dev)
+    if S > 0 and E > 0:
+        fn = getattr(lib, "vbmp_weighted_matsum_" + L.suffix(dt))
+        L.call(fn, "vbmp_weighted_matsum", L.ptr(Cc), L.ptr(wc), S, E, L.ptr(out), L.stream_ptr(dev))
+    return out.reshape(inner)

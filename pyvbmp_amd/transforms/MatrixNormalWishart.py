@@ -191,6 +191,12 @@ class MatrixNormalWishart():
                 C = C.reshape((1,) * (len(full) + 2 - C.ndim) + tuple(C.shape))
             shared = all(C.shape[nsd + i] == 1 for i in range(nmb))
             S = int(math.prod(sample_shape))
+            NBm = int(math.prod(mat_batch))
+            if (shared or nmb == 0) and NBm == 1:
+                # a single expert: one streaming pass over the covariances (K5b)
+                Cs = C.expand(sample_shape + (1,) * nmb + (d, d)).reshape(S, d, d)
+                ws = None if pw is None else pw.expand(full).reshape(S)
+                return ops.weighted_matsum(Cs, ws).reshape(mat_batch + (d, d))
             if shared and pw is not None and nmb > 0:
                 Cs = C.expand(sample_shape + (1,) * nmb + (d, d)).reshape(S, d * d)
                 W = pw.expand(full).reshape(S, -1)

@@ -175,3 +175,22 @@ def test_gmm_sample_sharded_matches_single(golden):
         assert_close(m.dist.invU.U, ref.dist.invU.U, 1e-10)
         assert_close(m.pi.alpha, ref.pi.alpha, 1e-10)
         assert_close(m.logZ, ref.logZ, 1e-10)
+
+
+@pytest.mark.parametrize("K,D,N", [(1, 64, 50001), (3, 40, 20000), (4, 16, 8191 * 2), (2, 33, 4097)])
+def test_weighted_moments_mfma_fp32(K, D, N):
+    """fp32 K4 on the matrix cores (v_mfma_f32_32x32x2_f32 over the sample axis) against an fp64 einsum"""
+    from pyvbmp_amd import ops
+    g = torch.Generator().manual_seed(K + D)
+    X = torch.randn(N, 1, D, generator=g, dtype=torch.float64)
+    p = torch.rand(N, K, generator=g, dtype=torch.float64)
+    Nk, SEx, SExx = ops.weighted_moments(X.float().to(DEV), p.float().to(DEV), 1, (K,))
+    Xs = X[:, 0]
+    assert_close(Nk, p.sum(0), 1e-5, what="N")
+    assert_close(SExx, torch.einsum("nk,ni,nj->kij", p, Xs, Xs), 2e-5, what="SExx")
+    ref_x = torch.einsum("nk,ni->ki", p, Xs)
+    assert float((SEx.cpu().double() - ref_x).abs().max()) < 2e-5 * float(p.sum(0).max())
+    # unit weights
+    Nk, SEx, SExx = ops.weighted_moments(X.float().to(DEV).expand(N, 1, D), None, 1, (1,))
+    assert_close(SExx[0], Xs.T @ Xs, 2e-5, what="SExx unit w")
+    assert abs(float(Nk[0]) - N) < 1e-3 * N
