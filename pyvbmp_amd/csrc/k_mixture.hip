@@ -190,6 +190,7 @@ __global__ __launch_bounds__(256) void k_wmom_mfma_f32(const float* __restrict__
         for (int r = 0; r < 16; ++r) acc[k][a][b][r] = 0.f;
     }
   }
+#pragma unroll 4
   for (int64_t pr = p0; pr < p1; ++pr) {
     const int64_t s = 2 * pr + half;
     const bool ok = s < S;
@@ -212,9 +213,15 @@ __global__ __launch_bounds__(256) void k_wmom_mfma_f32(const float* __restrict__
         for (int b = 0; b < NT; ++b) acc[k][a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(wx[a], x[b], acc[k][a][b], 0, 0, 0);
     }
   }
-  // C layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // The four waves of the block first combine in LDS (C layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)),
+  // so that one set of global float atomics leaves per BLOCK, not per wave (the chip-wide atomic rate is ~1.3 TB/s).
+  constexpr int DT = 32 * NT;
+  __shared__ float red[BO * (DT * DT + DT + 1)];
+  for (int e = threadIdx.x; e < BO * (DT * DT + DT + 1); e += 256) red[e] = 0.f;
+  __syncthreads();
 #pragma unroll
   for (int k = 0; k < BO; ++k) {
+    float* rk = red + k * (DT * DT + DT + 1);
 #pragma unroll
     for (int a = 0; a < NT; ++a)
 #pragma unroll
@@ -222,15 +229,26 @@ __global__ __launch_bounds__(256) void k_wmom_mfma_f32(const float* __restrict__
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int i = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * half, j = 32 * b + f;
-          if (i < D && j < D) atomicAdd(&SExx[((int64_t)k * D + i) * D + j], acc[k][a][b][r]);
+          atomicAdd(&rk[i * DT + j], acc[k][a][b][r]);
         }
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
       const float t = sx[k][a] + __shfl_xor(sx[k][a], 32, 64);
-      if (half == 0 && 32 * a + f < D) atomicAdd(&SEx[(int64_t)k * D + 32 * a + f], t);
+      if (half == 0) atomicAdd(&rk[DT * DT + 32 * a + f], t);
     }
-    float tn = sn[k] + __shfl_xor(sn[k], 32, 64);
-    if (lane == 0) atomicAdd(&Nk[k], tn);
+    const float tn = sn[k] + __shfl_xor(sn[k], 32, 64);
+    if (lane == 0) atomicAdd(&rk[DT * DT + DT], tn);
+  }
+  __syncthreads();
+  for (int k = 0; k < BO; ++k) {
+    const float* rk = red + k * (DT * DT + DT + 1);
+    for (int e = threadIdx.x; e < DT * DT; e += 256) {
+      const int i = e / DT, j = e % DT;
+      if (i < D && j < D) atomicAdd(&SExx[((int64_t)k * D + i) * D + j], rk[e]);
+    }
+    for (int e = threadIdx.x; e < DT; e += 256)
+      if (e < D) atomicAdd(&SEx[(int64_t)k * D + e], rk[DT * DT + e]);
+    if (threadIdx.x == 0) atomicAdd(&Nk[k], rk[DT * DT + DT]);
   }
 }
 
