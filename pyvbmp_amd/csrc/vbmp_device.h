@@ -526,4 +526,50 @@ __device__ __forceinline__ void gj_inverse(T (&a)[R][Dp], int lig, LogDet<T>& ld
     for (int j = 0; j < Dp; ++j) a[q][j] *= sc[q];
 }
 
+// ---------------------------------------------------------------- quadratic form + logdet only
+// q = e^T A^-1 e and log det A by forward elimination (LDL^T) with e carried as an extra column:
+// no back-substitution, no inverse, and at step k only the columns j > k are touched, i.e. about half of
+// the FMAs of the full Gauss-Jordan.  `a` and `e` are destroyed.  e is distributed like the rows
+// (entry row on the lane that owns the row).
+template <typename T, int Dp, int G, int R>
+__device__ __forceinline__ T elim_quad(T (&a)[R][Dp], T (&e)[R], int lig, LogDet<T>& ld) {
+  static_assert(R * G == Dp, "rows per lane x lanes per matrix must cover the padded dim");
+  T qacc = T(0);
+  static_for<0, Dp>([&](auto K) {
+    constexpr int k = decltype(K)::value;
+    constexpr int src = k % G, slot = k / G;
+    const bool owner = (G == 1) || (lig == src);
+    const T d = bcast<G, src>(a[slot][k]);
+    ld.mul(d);
+    const T p = rcp_nr(d);
+    const T ek = e[slot];
+    qacc += owner ? ek * ek * p : T(0);
+    static_for<0, R>([&](auto Q) {
+      constexpr int q = (decltype(Q)::value + slot + 1) % R;  // rows of the pivot slot last (DPP read-after-write)
+      const int row = lig + G * q;
+      const T nf = (row > k) ? -(a[q][k] * p) : T(0);
+      fmac_bcast<G, src>(e[q], e[slot], nf);
+      constexpr int c0 = (k + 1) / 4;  // 4-column chunks that still hold a column j > k
+      if constexpr (Dp % 4 == 0) {
+#pragma unroll
+        for (int c = c0; c < Dp / 4; ++c) {
+          if constexpr (q == slot)
+            fmac_self4<G, src>(&a[q][4 * c], nf);
+          else
+            fmac_bcast4<G, src>(&a[q][4 * c], &a[slot][4 * c], nf);
+        }
+      } else {
+#pragma unroll
+        for (int j = k + 1; j < Dp; ++j) a[q][j] = xfma(bcast<G, src>(a[slot][j]), nf, a[q][j]);
+      }
+    });
+  });
+  // sum of the owners' contributions over the lane group
+  if constexpr (G > 1) {
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) qacc += __shfl_xor(qacc, off, G);
+  }
+  return qacc;
+}
+
 }  // namespace vbmp
