@@ -244,7 +244,12 @@ class LinearDynamicalSystems():
 
         invSigma_t_t = self.BTRB_xp_xp
         Rc = self._compact(R, 2)  # the regressor is usually the constant bias column: keep it unexpanded
-        invSigmamu_t = self.BTR_xp_y @ Y - self.BTRB_xp_r @ Rc
+        if self.BTR_xp_y.ndim == 2:
+            # one shared (h x obs) map applied to T*S observations: a tall-skinny row-major GEMM (Y2 @ M^T) instead of a
+            # batched (h x obs)@(obs x 1) product per (t, series), which rocBLAS runs an order of magnitude slower
+            invSigmamu_t = (Y.squeeze(-1) @ _T(self.BTR_xp_y)).unsqueeze(-1) - self.BTRB_xp_r @ Rc
+        else:
+            invSigmamu_t = self.BTR_xp_y @ Y - self.BTRB_xp_r @ Rc
         # -1/2 y' invR y + y' (BTR_r_y' r) + const as ONE quadratic-form launch (K3a) instead of per-(t, series) bmm
         cst = 0.5 * self.obs_model.ElogdetinvSigma() - 0.5 * self.obs_dim * _LOG2PI
         lin = (_T(self.BTR_r_y) @ Rc).squeeze(-1)
