@@ -24,18 +24,29 @@ __device__ __forceinline__ void load_row(const T* __restrict__ x, int D, T (&r)[
   }
 }
 
-// -0.5 x^T P x + x^T b + c for one (x, component)
-template <typename T, int Dp>
+// -0.5 x^T P x + x^T b + c for one (x, component).  FULL (D == Dp): compile-time offsets, so a wave-uniform P
+// arrives through wide scalar loads; otherwise row guards only, columns clamped in-bounds against the zero padding of x.
+template <typename T, int Dp, bool FULL>
 __device__ __forceinline__ T quadform(const T (&x)[Dp], int D, const T* __restrict__ P, const T* __restrict__ b, T c) {
   T acc = T(0);
+  if constexpr (FULL) {
 #pragma unroll
-  for (int i = 0; i < Dp; ++i) {
-    if (i < D) {
+    for (int i = 0; i < Dp; ++i) {
       T row = T(0);
 #pragma unroll
-      for (int j = 0; j < Dp; ++j)
-        if (j < D) row = xfma(P[i * D + j], x[j], row);
+      for (int j = 0; j < Dp; ++j) row = xfma(P[i * Dp + j], x[j], row);
       acc = xfma(x[i], xfma(T(-0.5), row, b[i]), acc);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < Dp; ++i) {
+      if (i < D) {
+        const T* Pi = P + i * D;
+        T row = T(0);
+#pragma unroll
+        for (int j = 0; j < Dp; ++j) row = xfma(Pi[j < D ? j : D - 1], x[j], row);
+        acc = xfma(x[i], xfma(T(-0.5), row, b[i]), acc);
+      }
     }
   }
   return acc + c;
@@ -43,7 +54,7 @@ __device__ __forceinline__ T quadform(const T (&x)[Dp], int D, const T* __restri
 
 // ------------------------------------------------------------------------------------ K3a
 // out[s, bo, bi] = -1/2 x^T P x + x^T b + c,  x = X[s, bi, :],  (P, b, c)[bo, bi]
-template <typename T, int Dp>
+template <typename T, int Dp, bool FULL>
 __global__ __launch_bounds__(256) void k_quadform(const T* __restrict__ X, int64_t S, int64_t Bo, int64_t Bi, int D,
                                                   const T* __restrict__ P, const T* __restrict__ b,
                                                   const T* __restrict__ c, T* __restrict__ out) {
@@ -54,7 +65,7 @@ __global__ __launch_bounds__(256) void k_quadform(const T* __restrict__ X, int64
   load_row<T, Dp>(X + idx * D, D, x);
   for (int64_t bo = 0; bo < Bo; ++bo) {
     const int64_t comp = bo * Bi + bi;
-    out[(s * Bo + bo) * Bi + bi] = quadform<T, Dp>(x, D, P + comp * D * D, b + comp * D, c[comp]);
+    out[(s * Bo + bo) * Bi + bi] = quadform<T, Dp, FULL>(x, D, P + comp * D * D, b + comp * D, c[comp]);
   }
 }
 
@@ -63,52 +74,73 @@ __global__ __launch_bounds__(256) void k_quadform(const T* __restrict__ X, int64
 //   l[s,k] = quadform_k(x_s) (c_k already contains E log pi_k); lse_s = logsumexp_k l[s,k];
 //   p[s,k] = exp(l[s,k] - lse_s); NA[k] += p[s,k]; logZ += lse_s.
 // The p buffer doubles as the scratch for l.  NA / logZ must be zeroed by the caller.
-template <typename T, int Dp>
+template <typename T, int Dp, bool FULL>
 __global__ __launch_bounds__(256) void k_mixture_estep(const T* __restrict__ X, int64_t S, int K, int D,
                                                        const T* __restrict__ P, const T* __restrict__ b,
                                                        const T* __restrict__ c, T* __restrict__ p,
-                                                       T* __restrict__ NA, T* __restrict__ logZ) {
+                                                       T* __restrict__ NA, T* __restrict__ logZ, int stage) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* sNA = reinterpret_cast<T*>(smem_raw);  // K + 1 block partials
+  // stage != 0: the block's 256 x K responsibilities live in LDS (row stride K+1) between the two passes and leave
+  // as one contiguous coalesced store; otherwise the p buffer doubles as the scratch for l.
+  T* sL = sNA + (K + 1);
+  const int KS = K + 1;
   for (int k = threadIdx.x; k <= K; k += 256) sNA[k] = T(0);
   __syncthreads();
-  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const bool live = s < S;
-  T lse = T(0);
-  if (live) {
-    T x[Dp];
-    load_row<T, Dp>(X + s * D, D, x);
-    T* prow = p + s * K;
-    T mx = -INFINITY, sum = T(0);
-    for (int k = 0; k < K; ++k) {
-      const T l = quadform<T, Dp>(x, D, P + (int64_t)k * D * D, b + (int64_t)k * D, c[k]);
-      prow[k] = l;
-      if (l > mx) {
-        sum = sum * exp(mx - l) + T(1);
-        mx = l;
-      } else {
-        sum += exp(l - mx);
-      }
-    }
-    lse = mx + log(sum);
-  }
-  // second pass: normalise in place and reduce the responsibilities over the wave, then the block
   const int lane = threadIdx.x & 63;
-  for (int k = 0; k < K; ++k) {
-    T v = T(0);
+  // grid-stride over samples: the same-address global atomics at the end are per block, so the grid is capped
+  for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s - threadIdx.x < S; s += (int64_t)gridDim.x * 256) {
+    const bool live = s < S;
+    T* lrow = stage ? sL + threadIdx.x * KS : p + s * K;
+    T lse = T(0);
     if (live) {
-      T* prow = p + s * K;
-      v = exp(prow[k] - lse);
-      prow[k] = v;
+      T x[Dp];
+      load_row<T, Dp>(X + s * D, D, x);
+      T mx = -INFINITY, sum = T(0);
+      for (int k = 0; k < K; ++k) {
+        const T l = quadform<T, Dp, FULL>(x, D, P + (int64_t)k * D * D, b + (int64_t)k * D, c[k]);
+        if (stage) sL[threadIdx.x * KS + k] = l; else lrow[k] = l;
+        if (l > mx) {
+          sum = sum * exp(mx - l) + T(1);
+          mx = l;
+        } else {
+          sum += exp(l - mx);
+        }
+      }
+      lse = mx + log(sum);
     }
+    // second pass: normalise in place and reduce the responsibilities over the wave, then the block
+    for (int k = 0; k < K; ++k) {
+      T v = T(0);
+      if (live) {
+        if (stage) {
+          v = exp(sL[threadIdx.x * KS + k] - lse);
+          sL[threadIdx.x * KS + k] = v;
+        } else {
+          v = exp(lrow[k] - lse);
+          lrow[k] = v;
+        }
+      }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    if (lane == 0) atomicAdd(&sNA[k], v);
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) atomicAdd(&sNA[k], v);
+    }
+    T z = live ? lse : T(0);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off, 64);
+    if (lane == 0) atomicAdd(&sNA[K], z);
+    if (stage) {
+      __syncthreads();
+      const int64_t s0 = s - threadIdx.x;
+      const int64_t n = ((S - s0) < 256 ? (S - s0) : 256) * K;
+      T* dst = p + s0 * K;
+      for (int e = threadIdx.x; e < n; e += 256) {
+        const int r = e / K, k = e - r * K;
+        dst[e] = sL[r * KS + k];
+      }
+      __syncthreads();
+    }
   }
-  T z = live ? lse : T(0);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off, 64);
-  if (lane == 0) atomicAdd(&sNA[K], z);
   __syncthreads();
   for (int k = threadIdx.x; k < K; k += 256) atomicAdd(&NA[k], sNA[k]);
   if (threadIdx.x == 0) atomicAdd(logZ, sNA[K]);
@@ -157,91 +189,151 @@ __global__ __launch_bounds__(256) void k_weighted_moments(const T* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------ K4 on the matrix cores
-// fp32 weighted second moments  SExx[k] = sum_s w[s,k] x_s x_s^T  as an MFMA contraction over the SAMPLE axis
-// (the one place on this path where the contraction is genuinely dense; north star).  D <= 64, Bi == 1, Bo <= 4.
-// v_mfma_f32_32x32x2_f32 consumes two samples per instruction: A[i][k] = w_s x_s[i], B[k][j] = x_s[j] with
-// k = lane>>5 selecting the sample and lane&31 the feature, so every load is two 128-byte row segments.
-// The 64 x 64 result is a 2 x 2 grid of 32 x 32 accumulator tiles per component; sum w x and sum w ride along
-// on the VALU.  Each wave owns a contiguous slab of samples and adds its partial with float atomics
-// (2 x 128-byte segments per atomic instruction: the layout the memory-side atomics run at full rate for).
+// Weighted second moments  SExx[k] = sum_s w[s,k] x_s x_s^T  as an MFMA contraction over the SAMPLE axis (the one
+// place on this path where the contraction is genuinely dense).  A = (w x)^T, B = x, both ONE value per lane:
+//   16-tile forms (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32): lane -> (sample slot g = lane>>4, feature f = lane&15)
+//   32-tile form  (v_mfma_f32_32x32x2_f32):                          lane -> (g = lane>>5, f = lane&31)
+// so a wave consumes 64/TILE consecutive samples per instruction and the X loads are one contiguous run per wave.
+// Loads of U steps are issued branch-free ahead of the MFMAs (clamped addresses, zeroed weights past the end).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-template <int NT, int BO>  // NT = feature tiles of 32 (1 or 2), BO = components
-__global__ __launch_bounds__(256) void k_wmom_mfma_f32(const float* __restrict__ X, const float* __restrict__ p,
-                                                        int64_t S, int D, float* __restrict__ Nk,
-                                                        float* __restrict__ SEx, float* __restrict__ SExx) {
+template <typename T, int TILE> struct MomMfma;
+template <> struct MomMfma<double, 16> {
+  using acc_t = f64x4;
+  static constexpr int R = 4;
+  static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int r, int g) { return g + 4 * r; }
+};
+template <> struct MomMfma<float, 16> {
+  using acc_t = f32x4;
+  static constexpr int R = 4;
+  static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int r, int g) { return 4 * g + r; }
+};
+template <> struct MomMfma<float, 32> {
+  using acc_t = f32x16;
+  static constexpr int R = 16;
+  static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
+};
+
+template <typename T, int TILE, int NT, int BO>  // NT feature tiles of TILE, BO <= 4 components per pass
+__global__ __launch_bounds__(256) void k_wmom_mfma(const T* __restrict__ X, const T* __restrict__ p, int64_t S, int D,
+                                                    int ps, T* __restrict__ Nk, T* __restrict__ SEx,
+                                                    T* __restrict__ SExx) {
+  using M = MomMfma<T, TILE>;
+  using acc_t = typename M::acc_t;
+  constexpr int SPS = 64 / TILE, U = 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int half = lane >> 5, f = lane & 31;
+  const int g = lane / TILE, f = lane % TILE;
   const int64_t nw = (int64_t)gridDim.x * 4, w = (int64_t)blockIdx.x * 4 + wave;
-  // contiguous slab of sample pairs per wave
-  const int64_t pairs = (S + 1) / 2, per = (pairs + nw - 1) / nw;
-  const int64_t p0 = w * per, p1 = (p0 + per < pairs) ? p0 + per : pairs;
-  f32x16 acc[BO][NT][NT];
-  float sx[BO][NT], sn[BO];
+  // contiguous slab of steps per wave
+  const int64_t steps = (S + SPS - 1) / SPS, per = (steps + nw - 1) / nw;
+  const int64_t t0 = w * per, t1 = (t0 + per < steps) ? t0 + per : steps;
+  acc_t acc[BO][NT][NT];
+  T sx[BO][NT], sn[BO];
 #pragma unroll
   for (int k = 0; k < BO; ++k) {
-    sn[k] = 0.f;
+    sn[k] = T(0);
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
-      sx[k][a] = 0.f;
+      sx[k][a] = T(0);
 #pragma unroll
       for (int b = 0; b < NT; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[k][a][b][r] = 0.f;
+        for (int r = 0; r < M::R; ++r) acc[k][a][b][r] = T(0);
     }
   }
-#pragma unroll 4
-  for (int64_t pr = p0; pr < p1; ++pr) {
-    const int64_t s = 2 * pr + half;
-    const bool ok = s < S;
-    float x[NT];
+  // every 16-lane DPP row loads the BO weights of its sample in its first lanes; row_newbcast hands them out
+  const T* pp = p ? p : X;
+  const int pst = p ? ps : 0;
+  const int fk = p ? ((f & 15) < BO ? (f & 15) : BO - 1) : 0;
+  for (int64_t t = t0; t < t1; t += U) {
+    T x[U][NT], wp[U];
+    bool ok[U];
 #pragma unroll
-    for (int a = 0; a < NT; ++a) x[a] = (ok && 32 * a + f < D) ? X[s * D + 32 * a + f] : 0.f;
-#pragma unroll
-    for (int k = 0; k < BO; ++k) {
-      const float wk = ok ? (p ? p[s * BO + k] : 1.f) : 0.f;
-      sn[k] += wk;
-      float wx[NT];
+    for (int u = 0; u < U; ++u) {
+      const int64_t s = SPS * (t + u) + g;
+      ok[u] = (t + u < t1) && (s < S);
+      const int64_t sc = ok[u] ? s : 0;
 #pragma unroll
       for (int a = 0; a < NT; ++a) {
-        wx[a] = wk * x[a];
-        sx[k][a] += wx[a];
+        const int col = TILE * a + f;
+        x[u][a] = X[sc * D + (col < D ? col : 0)];
       }
+      wp[u] = pp[sc * pst + fk];
+    }
+    // all (always in-bounds) loads are in flight before the first use: the empty asm pins them outside the selects
 #pragma unroll
-      for (int a = 0; a < NT; ++a)
+    for (int u = 0; u < U; ++u) {
 #pragma unroll
-        for (int b = 0; b < NT; ++b) acc[k][a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(wx[a], x[b], acc[k][a][b], 0, 0, 0);
+      for (int a = 0; a < NT; ++a) asm volatile("" : "+v"(x[u][a]));
+      asm volatile("" : "+v"(wp[u]));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int a = 0; a < NT; ++a) x[u][a] = (ok[u] && TILE * a + f < D) ? x[u][a] : T(0);
+      wp[u] = ok[u] ? (p ? wp[u] : T(1)) : T(0);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      static_for<0, BO>([&](auto KC) {
+        constexpr int k = decltype(KC)::value;
+        const T wk = bcast<16, k>(wp[u]);
+        sn[k] += wk;
+        T wx[NT];
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+          wx[a] = wk * x[u][a];
+          sx[k][a] += wx[a];
+        }
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+          for (int b = 0; b < NT; ++b) acc[k][a][b] = M::run(wx[a], x[u][b], acc[k][a][b]);
+      });
     }
   }
-  // The four waves of the block first combine in LDS (C layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)),
-  // so that one set of global float atomics leaves per BLOCK, not per wave (the chip-wide atomic rate is ~1.3 TB/s).
-  constexpr int DT = 32 * NT;
-  __shared__ float red[BO * (DT * DT + DT + 1)];
-  for (int e = threadIdx.x; e < BO * (DT * DT + DT + 1); e += 256) red[e] = 0.f;
+  // The four waves of the block first combine in LDS, so that one set of global atomics leaves per BLOCK, not per wave
+  // (same-address float atomics serialise in L2; the chip-wide atomic rate is ~1.3 TB/s).
+  constexpr int DT = TILE * NT;
+  __shared__ T red[BO * (DT * DT + DT + 1)];
+  for (int e = threadIdx.x; e < BO * (DT * DT + DT + 1); e += 256) red[e] = T(0);
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < BO; ++k) {
-    float* rk = red + k * (DT * DT + DT + 1);
+    T* rk = red + k * (DT * DT + DT + 1);
 #pragma unroll
     for (int a = 0; a < NT; ++a)
 #pragma unroll
       for (int b = 0; b < NT; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int i = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * half, j = 32 * b + f;
-          atomicAdd(&rk[i * DT + j], acc[k][a][b][r]);
-        }
+        for (int r = 0; r < M::R; ++r)
+          atomicAdd(&rk[(TILE * a + M::row(r, g)) * DT + TILE * b + f], acc[k][a][b][r]);
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
-      const float t = sx[k][a] + __shfl_xor(sx[k][a], 32, 64);
-      if (half == 0) atomicAdd(&rk[DT * DT + 32 * a + f], t);
+      T tx = sx[k][a];
+#pragma unroll
+      for (int off = TILE; off < 64; off <<= 1) tx += __shfl_xor(tx, off, 64);
+      if (g == 0) atomicAdd(&rk[DT * DT + TILE * a + f], tx);
     }
-    const float tn = sn[k] + __shfl_xor(sn[k], 32, 64);
+    T tn = sn[k];
+#pragma unroll
+    for (int off = TILE; off < 64; off <<= 1) tn += __shfl_xor(tn, off, 64);
     if (lane == 0) atomicAdd(&rk[DT * DT + DT], tn);
   }
   __syncthreads();
   for (int k = 0; k < BO; ++k) {
-    const float* rk = red + k * (DT * DT + DT + 1);
+    const T* rk = red + k * (DT * DT + DT + 1);
     for (int e = threadIdx.x; e < DT * DT; e += 256) {
       const int i = e / DT, j = e % DT;
       if (i < D && j < D) atomicAdd(&SExx[((int64_t)k * D + i) * D + j], rk[e]);
@@ -252,19 +344,26 @@ __global__ __launch_bounds__(256) void k_wmom_mfma_f32(const float* __restrict__
   }
 }
 
-static int wmom_mfma_f32(const float* X, const float* p, int64_t S, int64_t Bo, int D, float* Nk, float* SEx, float* SExx,
-                         hipStream_t st) {
-  int64_t pairs = (S + 1) / 2;
-  int64_t blocks = (pairs + 4 * 64 - 1) / (4 * 64);  // >= 64 sample pairs per wave
+template <typename T, int TILE>
+static int wmom_mfma(const T* X, const T* p, int64_t S, int64_t Bo, int D, T* Nk, T* SEx, T* SExx, hipStream_t st) {
+  constexpr int SPS = 64 / TILE;
+  const int64_t steps = (S + SPS - 1) / SPS;
+  int64_t blocks = (steps + 4 * 64 - 1) / (4 * 64);  // >= 64 steps per wave
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
   const dim3 g((unsigned)blocks), b(256);
-#define VBMP_WM(NT, BO) hipLaunchKernelGGL((k_wmom_mfma_f32<NT, BO>), g, b, 0, st, X, p, S, D, Nk, SEx, SExx)
-  const int nt = D <= 32 ? 1 : 2;
-  if (nt == 1) {
-    if (Bo == 1) VBMP_WM(1, 1); else if (Bo == 2) VBMP_WM(1, 2); else if (Bo == 3) VBMP_WM(1, 3); else VBMP_WM(1, 4);
-  } else {
-    if (Bo == 1) VBMP_WM(2, 1); else if (Bo == 2) VBMP_WM(2, 2); else if (Bo == 3) VBMP_WM(2, 3); else VBMP_WM(2, 4);
+#define VBMP_WM(NT, BO)                                                                                          \
+  hipLaunchKernelGGL((k_wmom_mfma<T, TILE, NT, BO>), g, b, 0, st, X, p ? p + k0 : p, S, D, (int)Bo, Nk + k0,        \
+                     SEx + k0 * D, SExx + k0 * D * D)
+  const int nt = D <= TILE ? 1 : 2;
+  // components in groups of four per pass over X (accumulators live in registers)
+  for (int64_t k0 = 0; k0 < Bo; k0 += 4) {
+    const int64_t nb = Bo - k0 < 4 ? Bo - k0 : 4;
+    if (nt == 1) {
+      if (nb == 1) VBMP_WM(1, 1); else if (nb == 2) VBMP_WM(1, 2); else if (nb == 3) VBMP_WM(1, 3); else VBMP_WM(1, 4);
+    } else {
+      if (nb == 1) VBMP_WM(2, 1); else if (nb == 2) VBMP_WM(2, 2); else if (nb == 3) VBMP_WM(2, 3); else VBMP_WM(2, 4);
+    }
   }
 #undef VBMP_WM
   return hipGetLastError() == hipSuccess ? 0 : VBMP_ERR_LAUNCH;
@@ -278,7 +377,12 @@ static int quadform_dispatch(const T* X, int64_t S, int64_t Bo, int64_t Bi, int 
   hipStream_t st = (hipStream_t)stream;
   const int64_t blocks = (S * Bi + 255) / 256;
   VBMP_DISPATCH_DIM(T, D, {
-    hipLaunchKernelGGL((k_quadform<T, DP>), dim3((unsigned)blocks), dim3(256), 0, st, X, S, Bo, Bi, D, P, b, c, out);
+    if (D == DP)
+      hipLaunchKernelGGL((k_quadform<T, DP, true>), dim3((unsigned)blocks), dim3(256), 0, st, X, S, Bo, Bi, D, P, b, c,
+                         out);
+    else
+      hipLaunchKernelGGL((k_quadform<T, DP, false>), dim3((unsigned)blocks), dim3(256), 0, st, X, S, Bo, Bi, D, P, b, c,
+                         out);
     return hipGetLastError() == hipSuccess ? 0 : VBMP_ERR_LAUNCH;
   });
   return VBMP_ERR_ARG;
@@ -290,11 +394,19 @@ static int estep_dispatch(const T* X, int64_t S, int K, int D, const T* P, const
   if (S == 0) return 0;
   if (!X || !P || !b || !c || !p || !NA || !logZ || S < 0 || K < 1 || D < 1 || D > VBMP_MAX_DIM) return VBMP_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  const int64_t blocks = (S + 255) / 256;
-  const size_t smem = (size_t)(K + 1) * sizeof(T);
+  int64_t blocks = (S + 255) / 256;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  size_t smem = (size_t)(K + 1) * sizeof(T);
+  const size_t staged = (size_t)257 * (K + 1) * sizeof(T);
+  const int stage = staged <= 40 * 1024;
+  if (stage) smem = staged;
   VBMP_DISPATCH_DIM(T, D, {
-    hipLaunchKernelGGL((k_mixture_estep<T, DP>), dim3((unsigned)blocks), dim3(256), smem, st, X, S, K, D, P, b, c, p,
-                       NA, logZ);
+    if (D == DP)
+      hipLaunchKernelGGL((k_mixture_estep<T, DP, true>), dim3((unsigned)blocks), dim3(256), smem, st, X, S, K, D, P, b,
+                         c, p, NA, logZ, stage);
+    else
+      hipLaunchKernelGGL((k_mixture_estep<T, DP, false>), dim3((unsigned)blocks), dim3(256), smem, st, X, S, K, D, P, b,
+                         c, p, NA, logZ, stage);
     return hipGetLastError() == hipSuccess ? 0 : VBMP_ERR_LAUNCH;
   });
   return VBMP_ERR_ARG;
@@ -307,11 +419,14 @@ static int wmom_dispatch(const T* X, const T* p, int64_t S, int64_t Bo, int64_t 
   if (!X || !Nk || !SEx || !SExx || S < 0 || Bo < 0 || Bi < 0 || D < 1 || D > 2 * VBMP_MAX_DIM || Bi > 65535)
     return VBMP_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if constexpr (sizeof(T) == 4) {
-    // dense contraction over many samples: matrix cores (see k_wmom_mfma_f32)
-    if (Bi == 1 && Bo <= 4 && D <= 64 && S >= 4096)
-      return wmom_mfma_f32(reinterpret_cast<const float*>(X), reinterpret_cast<const float*>(p), S, Bo, D,
-                           reinterpret_cast<float*>(Nk), reinterpret_cast<float*>(SEx), reinterpret_cast<float*>(SExx), st);
+  // dense contraction over many samples: matrix cores (see k_wmom_mfma)
+  if (Bi == 1 && Bo <= 64 && S >= 4096) {
+    if constexpr (sizeof(T) == 4) {
+      if (D <= 16) return wmom_mfma<float, 16>(X, p, S, Bo, D, Nk, SEx, SExx, st);
+      if (D <= 64) return wmom_mfma<float, 32>(X, p, S, Bo, D, Nk, SEx, SExx, st);
+    } else {
+      if (D <= 32) return wmom_mfma<double, 16>(X, p, S, Bo, D, Nk, SEx, SExx, st);
+    }
   }
   // samples per block: as many as fit a 48 KiB LDS image of [x | 1 | w] rows (at most 256)
   int CH = (int)((48 * 1024) / ((size_t)(D + 2) * sizeof(T)));

@@ -60,7 +60,7 @@ def test_mixture_batched_golden(golden):
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
-@pytest.mark.parametrize("K,D,N", [(4, 16, 20011), (7, 3, 5000), (16, 32, 3001), (3, 40, 777)])
+@pytest.mark.parametrize("K,D,N", [(4, 16, 20011), (7, 3, 5000), (16, 32, 3001), (3, 40, 777), (40, 4, 3000)])
 def test_gmm_iteration_vs_oracle(K, D, N, dtype):
     """One full VB iteration (fused E-step K3, moments K4, update K2) against the oracle."""
     from oracle import mixture as omix
@@ -177,7 +177,7 @@ def test_gmm_sample_sharded_matches_single(golden):
         assert_close(m.logZ, ref.logZ, 1e-10)
 
 
-@pytest.mark.parametrize("K,D,N", [(1, 64, 50001), (3, 40, 20000), (4, 16, 8191 * 2), (2, 33, 4097)])
+@pytest.mark.parametrize("K,D,N", [(1, 64, 50001), (3, 40, 20000), (4, 16, 8191 * 2), (2, 33, 4097), (9, 16, 8192)])
 def test_weighted_moments_mfma_fp32(K, D, N):
     """fp32 K4 on the matrix cores (v_mfma_f32_32x32x2_f32 over the sample axis) against an fp64 einsum"""
     from pyvbmp_amd import ops
@@ -194,3 +194,17 @@ def test_weighted_moments_mfma_fp32(K, D, N):
     Nk, SEx, SExx = ops.weighted_moments(X.float().to(DEV).expand(N, 1, D), None, 1, (1,))
     assert_close(SExx[0], Xs.T @ Xs, 2e-5, what="SExx unit w")
     assert abs(float(Nk[0]) - N) < 1e-3 * N
+
+
+@pytest.mark.parametrize("K,D,N", [(1, 32, 30001), (4, 16, 50000), (3, 2, 9000), (2, 21, 4099), (11, 16, 8191), (6, 24, 5000)])
+def test_weighted_moments_mfma_fp64(K, D, N):
+    """fp64 K4 on v_mfma_f64_16x16x4_f64 against an einsum, at the fp64 parity tolerance"""
+    from pyvbmp_amd import ops
+    g = torch.Generator().manual_seed(K * 3 + D)
+    X = torch.randn(N, 1, D, generator=g, dtype=torch.float64) + 0.5
+    p = torch.rand(N, K, generator=g, dtype=torch.float64)
+    Nk, SEx, SExx = ops.weighted_moments(X.to(DEV), p.to(DEV), 1, (K,))
+    Xs = X[:, 0]
+    assert_close(Nk, p.sum(0), 1e-12, what="N")
+    assert_close(SExx, torch.einsum("nk,ni,nj->kij", p, Xs, Xs), 1e-12, what="SExx")
+    assert_close(SEx, torch.einsum("nk,ni->ki", p, Xs), 1e-12, what="SEx")

@@ -187,6 +187,25 @@ def bench_dmbd(args):
         print(f"dmbd {name}: T={T} S={S} n_obs={n_obs}: {dt_ * 1e3:.1f} ms / VB iteration, ELBO {float(m.ELBO_last):.4e}", flush=True)
 
 
+def bench_gmm(args):
+    """GMM at scale: fused E-step (K3), weighted moments (K4) and one full VB iteration, N samples, K=4, D=16."""
+    from pyvbmp_amd.models import GaussianMixtureModel
+    for dt in (torch.float64, torch.float32):
+        for K, D, N in ((4, 16, 4_000_000), (16, 16, 1_000_000), (4, 2, 8_000_000)):
+            g = torch.Generator(device="cuda").manual_seed(0)
+            X = torch.randn(N, D, generator=g, device="cuda", dtype=dt) + 3.0 * torch.randint(0, K, (N, 1), generator=g, device="cuda")
+            m = GaussianMixtureModel(K, D, device="cuda", dtype=dt)
+            m.update(X, iters=2)
+            es = X.element_size()
+            t_e = _time_call(lambda: m.update_assignments(X))
+            t_m = _time_call(lambda: m.dist.raw_moments(m._view(X), m.p))
+            t_it = _time_call(lambda: m.update(X, iters=1))
+            be, bm = (D + K) * es, (D + K) * es
+            print(f"gmm {str(dt)[6:]} K={K} D={D} N={N}: E-step {t_e:.3f} ms ({be * N / t_e / 1e6:.0f} GB/s, {be * N / t_e / 1e6 / 80:.1f}%)  "
+                  f"moments {t_m:.3f} ms ({bm * N / t_m / 1e6:.0f} GB/s, {bm * N / t_m / 1e6 / 80:.1f}%)  full iteration {t_it:.3f} ms "
+                  f"-> {N / t_it * 1e3:.3e} samples/s", flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="*", default=["niw"])
@@ -197,4 +216,4 @@ if __name__ == "__main__":
     ap.add_argument("--S", type=int, default=4096)
     args = ap.parse_args()
     for w in args.what:
-        {"niw": bench_niw, "copy": bench_copy, "mnw": bench_mnw, "lds": bench_lds, "dmbd": bench_dmbd}[w](args)
+        {"niw": bench_niw, "copy": bench_copy, "mnw": bench_mnw, "lds": bench_lds, "dmbd": bench_dmbd, "gmm": bench_gmm}[w](args)
