@@ -26,8 +26,25 @@ def _make(c):
     return m
 
 
+@pytest.fixture
+def smoother_form():
+    """K9 has two forms (row-per-lane for few series, lane-per-series for many); the debug switch of the library
+    forces one so that both meet the goldens whatever the series count."""
+    from pyvbmp_amd import _lib
+    lib = _lib.load()
+    lib.vbmp_debug_set_flags.argtypes = [__import__("ctypes").c_int]
+    lib.vbmp_debug_set_flags.restype = None
+
+    def force(form):
+        lib.vbmp_debug_set_flags({"rows": 0x20, "lanes": 0x10, "auto": 0}[form])
+    yield force
+    lib.vbmp_debug_set_flags(0)
+
+
+@pytest.mark.parametrize("form", ["rows", "lanes"])
 @pytest.mark.parametrize("case", LDS_CASES)
-def test_lds_golden(golden, case):
+def test_lds_golden(golden, case, form, smoother_form):
+    smoother_form(form)
     c = golden("lds")[case]
     m = _make(c)
     lr = float(c["lr"])
