@@ -123,7 +123,9 @@ int vbmp_weighted_moments_f32(const float* X, const float* p, int64_t S, int64_t
  * cu1 = QA_xp_u U[t], cu2 = ATQA_x_u U[t] (H-vectors) and cu3 = U[t]' ATQA_u_u U[t] carry the control input.
  * x0_res = -1/2 EXTinvUX + 1/2 ElogdetinvSigma - H/2 log 2pi of the initial-state prior (:349).
  * Outputs are dense: invSigma/Sigma/Sigma_t_tp1 (T,S,H,H), invSigmamu/mu (T,S,H), logZ (T,S),
- * Sigma_x0_x0 (S,H,H), mu_x0 (S,H).  All blocks must be 16-byte aligned. */
+ * Sigma_x0_x0 (S,H,H), mu_x0 (S,H).  All blocks must be 16-byte aligned.
+ * Two device forms, chosen by S: one series per 16-lane DPP row (S <= 32768: 4 series per wave, so that few
+ * thousand series already cover every SIMD) and one series per lane (more series). */
 #define VBMP_LDS_MAX_H 8
 #define VBMP_DECL_LDS_ARGS(SUF, REAL)                                                                         \
   typedef struct vbmp_lds_args_##SUF {                                                                     \
