@@ -340,27 +340,62 @@ __device__ __forceinline__ void tile_g2lds(const T* __restrict__ g, int64_t gstr
         *reinterpret_cast<typename TL::vec_t*>(&lds[m * TL::MS + row * TL::RS + cc * TL::V]) = v[i];
     }
   } else {
+    // generic D: same shape as the FULL path -- a compile-time trip count (that of the padded tile, in groups of at
+    // most 16), clamped loads issued ahead of the LDS writes, and the divisions by the runtime D done in float
+    // (exact here: indices < 4096, divisors <= 64)
+    const float inv_D = 1.0f / (float)D;
     const bool vec_ok = (gstride == DD) && (D % TL::V == 0) && ((reinterpret_cast<uintptr_t>(g) & 15) == 0);
     if (vec_ok) {
+      constexpr int NIT = (TL::MPW * Dp * Dp / TL::V + 63) / 64;
+      constexpr int GRP = NIT < 16 ? NIT : 16;
       const int nchunk = nm * DD / TL::V;  // chunks never straddle a row because D % V == 0
       const int cpr = D / TL::V;
+      const float inv_cpr = 1.0f / (float)cpr;
       const typename TL::vec_t* gv = reinterpret_cast<const typename TL::vec_t*>(g);
-      for (int c = lane; c < nchunk; c += 64) {
-        typename TL::vec_t v = gv[c];
-        int row_all = c / cpr;
-        int cc = c - row_all * cpr;
-        int m = row_all / D;
-        int row = row_all - m * D;
-        *reinterpret_cast<typename TL::vec_t*>(&lds[m * TL::MS + row * TL::RS + cc * TL::V]) = v;
+#pragma unroll
+      for (int i0 = 0; i0 < NIT; i0 += GRP) {
+        if (64 * i0 >= nchunk) break;  // wave-uniform
+        typename TL::vec_t v[GRP];
+#pragma unroll
+        for (int i = 0; i < GRP; ++i) {
+          const int c = lane + 64 * (i0 + i);
+          v[i] = gv[c < nchunk ? c : nchunk - 1];
+        }
+#pragma unroll
+        for (int i = 0; i < GRP; ++i) {
+          const int c = lane + 64 * (i0 + i);
+          const int row_all = (int)(((float)c + 0.5f) * inv_cpr);
+          const int cc = c - row_all * cpr;
+          const int m = (int)(((float)row_all + 0.5f) * inv_D);
+          const int row = row_all - m * D;
+          if (c < nchunk) *reinterpret_cast<typename TL::vec_t*>(&lds[m * TL::MS + row * TL::RS + cc * TL::V]) = v[i];
+        }
       }
     } else {
+      constexpr int NIT = (TL::MPW * Dp * Dp + 63) / 64;
+      constexpr int GRP = NIT < 16 ? NIT : 16;
       const int n = nm * DD;
-      for (int e = lane; e < n; e += 64) {
-        int m = e / DD;
-        int rem = e - m * DD;
-        int row = rem / D;
-        int col = rem - row * D;
-        lds[m * TL::MS + row * TL::RS + col] = g[(int64_t)m * gstride + rem];
+      const float inv_DD = 1.0f / (float)DD;
+#pragma unroll
+      for (int i0 = 0; i0 < NIT; i0 += GRP) {
+        if (64 * i0 >= n) break;  // wave-uniform
+        T v[GRP];
+#pragma unroll
+        for (int i = 0; i < GRP; ++i) {
+          const int e = lane + 64 * (i0 + i);
+          const int ec = e < n ? e : n - 1;
+          const int m = (int)(((float)ec + 0.5f) * inv_DD);
+          v[i] = g[(int64_t)m * gstride + (ec - m * DD)];
+        }
+#pragma unroll
+        for (int i = 0; i < GRP; ++i) {
+          const int e = lane + 64 * (i0 + i);
+          const int m = (int)(((float)e + 0.5f) * inv_DD);
+          const int rem = e - m * DD;
+          const int row = (int)(((float)rem + 0.5f) * inv_D);
+          const int col = rem - row * D;
+          if (e < n) lds[m * TL::MS + row * TL::RS + col] = v[i];
+        }
       }
     }
   }
@@ -400,26 +435,38 @@ __device__ __forceinline__ void tile_lds2g(T* __restrict__ g, int nm, int Drt, c
         if (lane + 64 * i < nchunk) gv[lane + 64 * i] = v[i];
     }
   } else {
+    const float inv_D = 1.0f / (float)D;
     const bool vec_ok = (D % TL::V == 0) && ((reinterpret_cast<uintptr_t>(g) & 15) == 0);
     if (vec_ok) {
+      constexpr int NIT = (TL::MPW * Dp * Dp / TL::V + 63) / 64;
       const int nchunk = nm * DD / TL::V;
       const int cpr = D / TL::V;
+      const float inv_cpr = 1.0f / (float)cpr;
       typename TL::vec_t* gv = reinterpret_cast<typename TL::vec_t*>(g);
-      for (int c = lane; c < nchunk; c += 64) {
-        int row_all = c / cpr;
-        int cc = c - row_all * cpr;
-        int m = row_all / D;
-        int row = row_all - m * D;
-        gv[c] = *reinterpret_cast<const typename TL::vec_t*>(&lds[m * TL::MS + row * TL::RS + cc * TL::V]);
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const int c = lane + 64 * i;
+        if (64 * i >= nchunk) break;  // wave-uniform
+        const int row_all = (int)(((float)c + 0.5f) * inv_cpr);
+        const int cc = c - row_all * cpr;
+        const int m = (int)(((float)row_all + 0.5f) * inv_D);
+        const int row = row_all - m * D;
+        if (c < nchunk)
+          gv[c] = *reinterpret_cast<const typename TL::vec_t*>(&lds[m * TL::MS + row * TL::RS + cc * TL::V]);
       }
     } else {
+      constexpr int NIT = (TL::MPW * Dp * Dp + 63) / 64;
       const int n = nm * DD;
-      for (int e = lane; e < n; e += 64) {
-        int m = e / DD;
-        int rem = e - m * DD;
-        int row = rem / D;
-        int col = rem - row * D;
-        g[e] = lds[m * TL::MS + row * TL::RS + col];
+      const float inv_DD = 1.0f / (float)DD;
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const int e = lane + 64 * i;
+        if (64 * i >= n) break;  // wave-uniform
+        const int m = (int)(((float)e + 0.5f) * inv_DD);
+        const int rem = e - m * DD;
+        const int row = (int)(((float)rem + 0.5f) * inv_D);
+        const int col = rem - row * D;
+        if (e < n) g[e] = lds[m * TL::MS + row * TL::RS + col];
       }
     }
   }
