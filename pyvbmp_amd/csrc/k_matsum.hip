@@ -20,17 +20,28 @@ __global__ __launch_bounds__(256) void k_weighted_matsum(const T* __restrict__ C
   if (vec_ok) {
     const int64_t ev = E / V;
     for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < ev; c += (int64_t)gridDim.x * 256) {
-      vec_t a0 = {}, a1 = {};
+      // eight independent 16-byte loads in flight per lane (the slab is streamed once: non-temporal)
+      constexpr int U = 8;
+      vec_t acc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc[u] = vec_t{};
       const vec_t* base = reinterpret_cast<const vec_t*>(C) + c;
       int64_t s = s0;
-      for (; s + 2 <= s1; s += 2) {  // two independent chains keep more loads in flight
-        const vec_t v0 = base[s * ev], v1 = base[(s + 1) * ev];
-        const T w0 = w ? w[s] : T(1), w1 = w ? w[s + 1] : T(1);
-        a0 += w0 * v0;
-        a1 += w1 * v1;
+      for (; s + U <= s1; s += U) {
+        vec_t v[U];
+        T ww[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          v[u] = __builtin_nontemporal_load(&base[(s + u) * ev]);
+          ww[u] = w ? w[s + u] : T(1);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] += ww[u] * v[u];
       }
-      if (s < s1) a0 += (w ? w[s] : T(1)) * base[s * ev];
-      a0 += a1;
+      for (; s < s1; ++s) acc[0] += (w ? w[s] : T(1)) * base[s * ev];
+#pragma unroll
+      for (int u = 1; u < U; ++u) acc[0] += acc[u];
+      const vec_t a0 = acc[0];
 #pragma unroll
       for (int u = 0; u < V; ++u) atomicAdd(&out[c * V + u], a0[u]);
     }
@@ -51,8 +62,9 @@ static int matsum_dispatch(const T* C, const T* w, int64_t S, int64_t E, T* out,
   int64_t bx = (E / V + 255) / 256;
   if (bx < 1) bx = 1;
   if (bx > 64) bx = 64;
-  // enough sample slabs to fill the chip (>= 2048 blocks), at least 32 samples each
-  int64_t by = (2048 + bx - 1) / bx;
+  // enough sample slabs to fill the chip (>= 1024 blocks of 256 lanes x 8 loads in flight), at least 32 samples
+  // each; few slabs keep the same-address atomics of the final combine short
+  int64_t by = (1024 + bx - 1) / bx;
   int64_t chunk = (S + by - 1) / by;
   if (chunk < 32) chunk = 32;
   by = (S + chunk - 1) / chunk;

@@ -111,9 +111,9 @@ def bench_mnw(args):
     print(f"mnw.forward  N={N} n=p=32 fp32: {t:.3f} ms -> {N / t * 1e3:.3e} msgs/s, {bpm * N / t / 1e6:.1f} GB/s alg ({bpm * N / t / 1e6 / 80:.1f}% of 8 TB/s)", flush=True)
     t = _time_call(lambda: m.backward(VF(invSigma=Py, invSigmamu=ey)))
     print(f"mnw.backward N={N} n=p=32 fp32: {t:.3f} ms -> {N / t * 1e3:.3e} msgs/s, {bpm * N / t / 1e6:.1f} GB/s alg ({bpm * N / t / 1e6 / 80:.1f}% of 8 TB/s)", flush=True)
-    Sx = torch.linalg.inv(Px)
+    Sx = torch.linalg.inv(Px).contiguous()  # LU inverse comes back column-major; messages on the path are row-major
     mux = Sx @ ex
-    Sy = torch.linalg.inv(Py)
+    Sy = torch.linalg.inv(Py).contiguous()
     muy = Sy @ ey
     bpu = (p * p + p + n * n + n) * 4
     t = _time_call(lambda: m.update(VF(mu=mux, Sigma=Sx), VF(mu=muy, Sigma=Sy)))
