@@ -36,6 +36,31 @@ def test_spd_inv_logdet_vs_oracle(D, dtype):
         assert_close(ld, ref_ld, _tol(dtype), what=f"logdet D={D} B={B}")
 
 
+@pytest.mark.parametrize("D", [33, 47, 64])
+def test_spd_inv_large_dim_both_forms(D):
+    """D > 32 runs one block per matrix for small batches and one wave per matrix for large ones; the debug switch forces either.
+    Both against LU, with a batch larger than the grid (grid-stride loop) and a non-SPD member."""
+    import ctypes
+    from pyvbmp_amd import ops, _lib
+    lib = _lib.load()
+    lib.vbmp_debug_set_flags.argtypes = [ctypes.c_int]
+    lib.vbmp_debug_set_flags.restype = None
+    B = 2500
+    A = _spd(B, D, torch.float64, seed=77 + D)
+    A[5] = -A[5]  # det sign (-1)^D
+    ref_inv, ref_ld = torch.linalg.inv(A), torch.logdet(A)
+    try:
+        for flag in (0x80, 0x40):
+            lib.vbmp_debug_set_flags(flag)
+            cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
+            Ainv, ld = ops.spd_inv_logdet(A.to(DEV), nonspd=cnt)
+            assert_close(Ainv, ref_inv, TOL64, what=f"inverse flag={flag}")
+            assert_close(ld, ref_ld, TOL64, what=f"logdet flag={flag}")
+            assert int(cnt.item()) == 1
+    finally:
+        lib.vbmp_debug_set_flags(0)
+
+
 def test_spd_inv_batch_shapes_and_empty():
     from pyvbmp_amd import ops
     A = _spd(30, 6, torch.float64, 5).reshape(2, 3, 5, 6, 6)
