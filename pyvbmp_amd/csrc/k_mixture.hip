@@ -4,6 +4,9 @@
 #include "vbmp_dispatch.h"
 #include "../../include/vbmp_hip.h"
 
+extern "C" int g_vbmp_flags;
+extern "C" int g_vbmp_blocks_per_cu;
+
 namespace vbmp {
 
 // one sample row in registers (zero padded to Dp)
@@ -349,7 +352,8 @@ static int wmom_mfma(const T* X, const T* p, int64_t S, int64_t Bo, int D, T* Nk
   constexpr int SPS = 64 / TILE;
   const int64_t steps = (S + SPS - 1) / SPS;
   int64_t blocks = (steps + 4 * 64 - 1) / (4 * 64);  // >= 64 steps per wave
-  if (blocks > 1024) blocks = 1024;
+  const int64_t cap = g_vbmp_blocks_per_cu > 0 ? 256 * (int64_t)g_vbmp_blocks_per_cu : 1024;  // debug override
+  if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   const dim3 g((unsigned)blocks), b(256);
 #define VBMP_WM(NT, BO)                                                                                          \
@@ -369,12 +373,210 @@ static int wmom_mfma(const T* X, const T* p, int64_t S, int64_t Bo, int D, T* Nk
   return hipGetLastError() == hipSuccess ? 0 : VBMP_ERR_LAUNCH;
 }
 
+// ------------------------------------------------------------------------------------ K3a / K3 on the matrix cores
+// out[s,bo,bi] = -1/2 x'Px + x'b + c for 16 samples at a time:  (P x_j)_i = sum_f P[i][f] x_j[f]  is the 16x16x4 MFMA
+// with A = P (rows i = feature out, LDS resident in operand order), B = X^T (k = feature in, column j = sample), so
+// C[i][j] lands with rows = features and columns = samples, and the C rows a lane holds are exactly the features
+// whose x values the lane already carries as its B operands (the k-slot -> feature map FEAT is chosen per dtype to
+// make that true: f64 C rows are q + 4r, f32 C rows are 4q + r, q = lane >> 4).  The quadratic form is then a
+// 4*DT-term dot product per lane plus two cross-lane adds.  C starts at -2b, so  l = -1/2 x'(Px - 2b) + c.
+// Grid: x = groups of sample tiles, y = bi (inner component axis: its own X slice and its own parameters),
+// z = chunks of BC outer components whose P fit in LDS together.
+template <typename T> struct QfMfma;
+template <> struct QfMfma<double> {
+  using acc_t = f64x4;
+  static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __host__ __forceinline__ int feat(int q, int t) { return q + 4 * t; }
+};
+template <> struct QfMfma<float> {
+  using acc_t = f32x4;
+  static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __host__ __forceinline__ int feat(int q, int t) { return 4 * q + t; }
+};
+
+template <typename T, int DT>  // DT = ceil(D / 16) feature blocks
+__global__ __launch_bounds__(256) void k_quadform_mfma(const T* __restrict__ X, int64_t S, int64_t Bo, int64_t Bi, int D,
+                                                       const T* __restrict__ P, const T* __restrict__ b,
+                                                       const T* __restrict__ c, T* __restrict__ out, int BC,
+                                                       int64_t tiles_per_block) {
+  using M = QfMfma<T>;
+  using acc_t = typename M::acc_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* sP = reinterpret_cast<T*>(smem_raw);      // [e][a][b][t][lane]
+  T* sB = sP + (size_t)BC * DT * DT * 4 * 64;  // [e][a][lane][r] = -2 b[feat(q,r) + 16a]
+  T* sC = sB + (size_t)BC * DT * 64 * 4;       // [e]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, j = lane & 15;
+  const int64_t bi = blockIdx.y;
+  const int bo0 = blockIdx.z * BC;
+  const int nb = (Bo - bo0) < BC ? (int)(Bo - bo0) : BC;
+  constexpr int PE = DT * DT * 4 * 64;
+  for (int idx = threadIdx.x; idx < nb * PE; idx += 256) {
+    const int e = idx / PE, rem = idx - e * PE;
+    const int l = rem & 63, t = (rem >> 6) & 3, bb = (rem >> 8) % DT, a = (rem >> 8) / DT;
+    const int i = (l & 15) + 16 * a, f = M::feat(l >> 4, t) + 16 * bb;
+    const int64_t comp = (int64_t)(bo0 + e) * Bi + bi;
+    sP[idx] = (i < D && f < D) ? P[comp * D * D + (int64_t)i * D + f] : T(0);
+  }
+  for (int idx = threadIdx.x; idx < nb * DT * 256; idx += 256) {
+    const int e = idx / (DT * 256), rem = idx - e * (DT * 256);
+    const int r = rem & 3, l = (rem >> 2) & 63, a = rem >> 8;
+    const int i = M::feat(l >> 4, r) + 16 * a;
+    const int64_t comp = (int64_t)(bo0 + e) * Bi + bi;
+    sB[idx] = (i < D) ? T(-2) * b[comp * D + i] : T(0);
+  }
+  for (int e = threadIdx.x; e < nb; e += 256) sC[e] = c[(int64_t)(bo0 + e) * Bi + bi];
+  __syncthreads();
+  const int64_t ntiles = (S + 15) / 16;
+  const int64_t t_lo = (int64_t)blockIdx.x * tiles_per_block;
+  const int64_t t_hi = (t_lo + tiles_per_block < ntiles) ? t_lo + tiles_per_block : ntiles;
+  for (int64_t tile = t_lo + wave; tile < t_hi; tile += 4) {
+    const int64_t s = tile * 16 + j;
+    const bool ok = s < S;
+    const T* xrow = X + ((ok ? s : S - 1) * Bi + bi) * D;
+    T x[DT][4];
+#pragma unroll
+    for (int bb = 0; bb < DT; ++bb)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int f = M::feat(q, t) + 16 * bb;
+        x[bb][t] = xrow[f < D ? f : 0];
+      }
+#pragma unroll
+    for (int bb = 0; bb < DT; ++bb)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(x[bb][t]));  // loads stay unconditional and batched
+#pragma unroll
+    for (int bb = 0; bb < DT; ++bb)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) x[bb][t] = (M::feat(q, t) + 16 * bb < D) ? x[bb][t] : T(0);
+    // four components per round: lane group q keeps the value of component 4g + q, so that one store instruction
+    // writes 16 samples x 4 adjacent components
+    for (int e0 = 0; e0 < nb; e0 += 4) {
+      T keep = T(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u;
+        if (e < nb) {  // wave-uniform
+          const T* pe = sP + (size_t)e * PE + lane;
+          const acc_t* be = reinterpret_cast<const acc_t*>(sB + ((size_t)e * DT * 64 + lane) * 4);
+          T v = T(0);
+#pragma unroll
+          for (int a = 0; a < DT; ++a) {
+            acc_t acc = be[a * 64];
+#pragma unroll
+            for (int bb = 0; bb < DT; ++bb)
+#pragma unroll
+              for (int t = 0; t < 4; ++t) acc = M::run(pe[((a * DT + bb) * 4 + t) * 64], x[bb][t], acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v = xfma(acc[r], x[a][r], v);
+          }
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          const T val = T(-0.5) * v + sC[e];
+          keep = (q == u) ? val : keep;
+        }
+      }
+      const int eq = e0 + q;
+      if (ok && eq < nb) out[(s * Bo + bo0 + eq) * Bi + bi] = keep;
+    }
+  }
+}
+
+// second half of the mixture E-step when the log-likelihoods were produced by k_quadform_mfma:
+// p[s,:] <- softmax(p[s,:]) in place, NA[k] += p[s,k], logZ += logsumexp.  One lane per sample, rows staged
+// through LDS so that the global traffic is coalesced.
+template <typename T>
+__global__ __launch_bounds__(256) void k_estep_softmax(T* __restrict__ p, int64_t S, int K, T* __restrict__ NA,
+                                                       T* __restrict__ logZ) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* sNA = reinterpret_cast<T*>(smem_raw);  // K + 1
+  T* sL = sNA + (K + 1);                    // 256 x (K + 1)
+  const int KS = K + 1;
+  for (int k = threadIdx.x; k <= K; k += 256) sNA[k] = T(0);
+  const int lane = threadIdx.x & 63;
+  for (int64_t s0 = (int64_t)blockIdx.x * 256; s0 < S; s0 += (int64_t)gridDim.x * 256) {
+    const int64_t n = ((S - s0) < 256 ? (S - s0) : 256) * K;
+    T* src = p + s0 * K;
+    __syncthreads();
+    for (int e = threadIdx.x; e < n; e += 256) {
+      const int r = e / K, k = e - r * K;
+      sL[r * KS + k] = src[e];
+    }
+    __syncthreads();
+    const bool live = s0 + threadIdx.x < S;
+    T* row = sL + threadIdx.x * KS;
+    T mx = -INFINITY;
+    if (live)
+      for (int k = 0; k < K; ++k) mx = row[k] > mx ? row[k] : mx;
+    T sum = T(0);
+    if (live)
+      for (int k = 0; k < K; ++k) sum += exp(row[k] - mx);
+    const T lse = live ? mx + log(sum) : T(0);
+    for (int k = 0; k < K; ++k) {
+      T v = T(0);
+      if (live) {
+        v = exp(row[k] - lse);
+        row[k] = v;
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) atomicAdd(&sNA[k], v);
+    }
+    T z = lse;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off, 64);
+    if (lane == 0) atomicAdd(&sNA[K], z);
+    __syncthreads();
+    for (int e = threadIdx.x; e < n; e += 256) {
+      const int r = e / K, k = e - r * K;
+      src[e] = sL[r * KS + k];
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += 256) atomicAdd(&NA[k], sNA[k]);
+  if (threadIdx.x == 0) atomicAdd(logZ, sNA[K]);
+}
+
+// launch of the MFMA quadratic form; returns false when the shape is not served (caller falls back to k_quadform)
+template <typename T>
+static bool quadform_mfma_launch(const T* X, int64_t S, int64_t Bo, int64_t Bi, int D, const T* P, const T* b,
+                                 const T* c, T* out, hipStream_t st) {
+  if (D < 8 || D > 64 || S * Bi < 2048 || Bi > 65535) return false;
+  const int DT = (D + 15) / 16;
+  const size_t per = ((size_t)DT * DT * 256 + (size_t)DT * 256 + 1) * sizeof(T);
+  int BC = (int)((size_t)(56 * 1024) / per);
+  if (BC < 1) return false;
+  if (BC > 32) BC = 32;
+  if (BC > Bo) BC = (int)Bo;
+  const int64_t nz = (Bo + BC - 1) / BC;
+  if (nz > 65535) return false;
+  const int64_t ntiles = (S + 15) / 16;
+  // enough blocks to fill the chip, but every block pays for staging its P chunk: at least 32 tiles per block
+  int64_t want = (256 * 8) / (Bi * nz);
+  if (want < 1) want = 1;
+  int64_t tpb = (ntiles + want - 1) / want;
+  if (tpb < 32) tpb = 32;
+  const int64_t gx = (ntiles + tpb - 1) / tpb;
+  const dim3 g((unsigned)gx, (unsigned)Bi, (unsigned)nz), blk(256);
+  const size_t smem = per * BC;
+#define VBMP_QF(DTV) hipLaunchKernelGGL((k_quadform_mfma<T, DTV>), g, blk, smem, st, X, S, Bo, Bi, D, P, b, c, out, BC, tpb)
+  if (DT == 1) VBMP_QF(1); else if (DT == 2) VBMP_QF(2); else if (DT == 3) VBMP_QF(3); else VBMP_QF(4);
+#undef VBMP_QF
+  return true;
+}
+
 template <typename T>
 static int quadform_dispatch(const T* X, int64_t S, int64_t Bo, int64_t Bi, int D, const T* P, const T* b, const T* c,
                              T* out, void* stream) {
   if (S == 0 || Bo == 0 || Bi == 0) return 0;
   if (!X || !P || !b || !c || !out || S < 0 || Bo < 0 || Bi < 0 || D < 1 || D > VBMP_MAX_DIM) return VBMP_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
+  if (!(g_vbmp_flags & 0x100) && quadform_mfma_launch<T>(X, S, Bo, Bi, D, P, b, c, out, st))  // 0x100: VALU form only
+    return hipGetLastError() == hipSuccess ? 0 : VBMP_ERR_LAUNCH;
   const int64_t blocks = (S * Bi + 255) / 256;
   VBMP_DISPATCH_DIM(T, D, {
     if (D == DP)
@@ -396,6 +598,13 @@ static int estep_dispatch(const T* X, int64_t S, int K, int D, const T* P, const
   hipStream_t st = (hipStream_t)stream;
   int64_t blocks = (S + 255) / 256;
   if (blocks > 256 * 8) blocks = 256 * 8;
+  // D >= 8: log-likelihoods on the matrix cores into the p buffer, then the in-place softmax pass
+  if (!(g_vbmp_flags & 0x100) && (size_t)257 * (K + 1) * sizeof(T) <= 60 * 1024 &&
+      quadform_mfma_launch<T>(X, S, K, 1, D, P, b, c, p, st)) {
+    hipLaunchKernelGGL((k_estep_softmax<T>), dim3((unsigned)blocks), dim3(256), (size_t)257 * (K + 1) * sizeof(T), st, p,
+                       S, K, NA, logZ);
+    return hipGetLastError() == hipSuccess ? 0 : VBMP_ERR_LAUNCH;
+  }
   size_t smem = (size_t)(K + 1) * sizeof(T);
   const size_t staged = (size_t)257 * (K + 1) * sizeof(T);
   const int stage = staged <= 40 * 1024;

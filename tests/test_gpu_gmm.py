@@ -208,3 +208,54 @@ def test_weighted_moments_mfma_fp64(K, D, N):
     assert_close(Nk, p.sum(0), 1e-12, what="N")
     assert_close(SExx, torch.einsum("nk,ni,nj->kij", p, Xs, Xs), 1e-12, what="SExx")
     assert_close(SEx, torch.einsum("nk,ni->ki", p, Xs), 1e-12, what="SEx")
+
+
+def _quad_ref(X, P, b, c):
+    """X (S,Bi,D), P (Bo,Bi,D,D), b (Bo,Bi,D), c (Bo,Bi) -> (S,Bo,Bi) in fp64 on the CPU"""
+    X, P, b, c = X.double(), P.double(), b.double(), c.double()
+    q = torch.einsum("sid,oide,sie->soi", X, P, X)
+    return -0.5 * q + torch.einsum("sid,oid->soi", X, b) + c
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("S,Bo,Bi,D", [(4099, 4, 1, 16), (3000, 3, 2, 9), (2500, 33, 1, 12), (2100, 2, 3, 40),
+                                        (2304, 5, 1, 64), (2050, 1, 1, 57), (5000, 7, 1, 8)])
+def test_quadform_mfma_and_valu_forms(S, Bo, Bi, D, dtype, smoother_flags):
+    """K3a on the matrix cores (D >= 8, enough samples) and its VALU form (debug switch 0x100) against an einsum:
+    padded feature blocks, component chunks (Bo > 32), inner component axes with their own X slice."""
+    from pyvbmp_amd import ops
+    g = torch.Generator().manual_seed(S + D)
+    X = torch.randn(S, Bi, D, generator=g, dtype=torch.float64)
+    A = torch.randn(Bo, Bi, D, D + 2, generator=g, dtype=torch.float64)
+    P = A @ A.transpose(-2, -1) / D + torch.randn(Bo, Bi, D, D, generator=g, dtype=torch.float64) * 0.05  # not symmetric
+    b = torch.randn(Bo, Bi, D, generator=g, dtype=torch.float64)
+    c = torch.randn(Bo, Bi, generator=g, dtype=torch.float64)
+    ref = _quad_ref(X, P, b, c)
+    tol = 1e-12 if dtype == torch.float64 else 2e-5
+    for flag in (0, 0x100):
+        smoother_flags(flag)
+        out = ops.quadform_loglike(X[:, None].to(DEV, dtype), P.to(DEV, dtype), b.to(DEV, dtype), c.to(DEV, dtype))
+        assert out.shape == (S, Bo, Bi)
+        assert_close(out, ref, tol, what=f"flag={flag}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("S,K,D", [(4099, 4, 16), (2500, 33, 12), (3001, 6, 40), (2048, 2, 64)])
+def test_mixture_estep_mfma_and_valu_forms(S, K, D, dtype, smoother_flags):
+    from pyvbmp_amd import ops
+    g = torch.Generator().manual_seed(S + K)
+    X = torch.randn(S, D, generator=g, dtype=torch.float64)
+    A = torch.randn(K, D, D + 2, generator=g, dtype=torch.float64)
+    P = A @ A.transpose(-2, -1) / D
+    b = torch.randn(K, D, generator=g, dtype=torch.float64)
+    c = torch.randn(K, generator=g, dtype=torch.float64)
+    l = _quad_ref(X[:, None], P[:, None], b[:, None], c[:, None])[..., 0]
+    lse = torch.logsumexp(l, -1)
+    pref = torch.exp(l - lse[:, None])
+    tol = 1e-11 if dtype == torch.float64 else 1e-4
+    for flag in (0, 0x100):
+        smoother_flags(flag)
+        p, NA, logZ = ops.mixture_estep(X.to(DEV, dtype), P.to(DEV, dtype), b.to(DEV, dtype), c.to(DEV, dtype))
+        assert_close(p, pref, tol, what=f"p flag={flag}")
+        assert_close(NA, pref.sum(0), tol, what=f"NA flag={flag}")
+        assert_close(logZ, lse.sum(), tol, what=f"logZ flag={flag}")
