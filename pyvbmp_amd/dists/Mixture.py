@@ -80,7 +80,15 @@ class Mixture():
         self.dist.ss_update(SExx, SEx, N, lr, None)
         return ELBO
 
-    def update(self, X, iters=1, lr=1.0, verbose=False):
+    def update(self, X, iters=1, lr=1.0, verbose=False, graphed=False):
+        """VB iterations (ref dists/Mixture.py:47-58).  graphed=True replays the iteration as one HIP graph
+        (pyvbmp_amd.graph): for small, launch-bound problems; not with verbose (printing synchronises) nor with a
+        multi-rank reducer (collectives stay outside graphs here)."""
+        if graphed and not verbose and (self.reducer is None or self.reducer.world_size == 1):
+            from .. import graph
+            key = (X.data_ptr(), tuple(X.shape), X.dtype, float(lr))
+            graph.run_iterations(self, lambda: self.update(X, iters=1, lr=lr), iters, key)
+            return
         for i in range(iters):
             if self.reducer is not None:
                 ELBO = self._update_sharded(X, lr)

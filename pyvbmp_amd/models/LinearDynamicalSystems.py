@@ -99,8 +99,16 @@ class LinearDynamicalSystems():
         return y, u, r
 
     # ------------------------------------------------------------------ VB loop
-    def update(self, y, u=None, r=None, p=None, iters=1, lr=1.0, verbose=False):
-        L = -torch.tensor(torch.inf, device=self.device, dtype=self.dtype)
+    def update(self, y, u=None, r=None, p=None, iters=1, lr=1.0, verbose=False, graphed=False):
+        """VB iterations (ref models/LinearDynamicalSystems.py:85-102).  graphed=True replays the iteration as one
+        HIP graph (pyvbmp_amd.graph) -- for short / few series, where the iteration is launch-bound; not with
+        verbose (printing synchronises) nor with a multi-rank reducer."""
+        if graphed and not verbose and (self.reducer is None or self.reducer.world_size == 1):
+            from .. import graph
+            key = tuple((t.data_ptr(), tuple(t.shape), t.dtype) if t is not None else None for t in (y, u, r, p)) + (float(lr),)
+            graph.run_iterations(self, lambda: self.update(y, u, r, p, iters=1, lr=lr), iters, key)
+            return
+        L = torch.full((), -torch.inf, device=self.device, dtype=self.dtype)
         L_last = L
         y, u, r = self.reshape_inputs(y, u, r)
         for i in range(iters):

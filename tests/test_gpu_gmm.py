@@ -259,3 +259,27 @@ def test_mixture_estep_mfma_and_valu_forms(S, K, D, dtype, smoother_flags):
         assert_close(p, pref, tol, what=f"p flag={flag}")
         assert_close(NA, pref.sum(0), tol, what=f"NA flag={flag}")
         assert_close(logZ, lse.sum(), tol, what=f"logZ flag={flag}")
+
+
+def test_gmm_graphed_update_matches_eager():
+    """hipGraph replay of the VB iteration (pyvbmp_amd.graph) against the eager loop: same state after the same number
+    of iterations (order of the atomic sums differs: 1e-9), also after an eager update in between and a second call."""
+    from pyvbmp_amd.models import GaussianMixtureModel
+    g = torch.Generator().manual_seed(3)
+    X = torch.cat((torch.randn(300, 2, generator=g, dtype=torch.float64) + 3.0,
+                   torch.randn(300, 2, generator=g, dtype=torch.float64) - 2.0)).to(DEV)
+    models = []
+    for graphed in (False, True):
+        torch.manual_seed(5)
+        m = GaussianMixtureModel(4, 2, device=DEV, dtype=torch.float64)
+        m.update(X, iters=7, lr=1.0, graphed=graphed)
+        m.update(X, iters=1, lr=1.0)               # eager step in between rebinds the state
+        m.update(X, iters=4, lr=1.0, graphed=graphed)  # cached graph, state synced back in
+        models.append(m)
+    a, b = models
+    for f in ("mu", "lambda_mu"):
+        assert_close(getattr(b.dist, f), getattr(a.dist, f), 1e-9, what=f)
+    assert_close(b.dist.invU.invU, a.dist.invU.invU, 1e-9, what="invU")
+    assert_close(b.pi.alpha, a.pi.alpha, 1e-9, what="alpha")
+    assert_close(b.p, a.p, 1e-9, what="p")
+    assert_close(b.ELBO(), a.ELBO(), 1e-9, what="ELBO")

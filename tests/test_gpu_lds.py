@@ -157,3 +157,23 @@ def test_lds_hidden_12_runs():
         m.update(y, iters=1)
         e.append(float(m.ELBO_last))
     assert all(torch.isfinite(torch.tensor(e))) and e[-1] > e[0]
+
+
+@pytest.mark.parametrize("noise", ["shared", "independent"])
+def test_lds_graphed_update_matches_eager(noise):
+    """hipGraph replay of the LDS VB iteration (pyvbmp_amd.graph) against the eager loop on a short Lorenz-like set"""
+    from pyvbmp_amd.models import LinearDynamicalSystems
+    g = torch.Generator().manual_seed(11)
+    y = lorenz(60, 9, g).to(DEV)
+    out = []
+    for graphed in (False, True):
+        torch.manual_seed(2)
+        m = LinearDynamicalSystems((6,), 4, latent_noise=noise, device=DEV, dtype=torch.float64)
+        m.update(y, iters=6, lr=1.0, graphed=graphed)
+        out.append(m)
+    a, b = out
+    assert_close(b.px.mu, a.px.mu, 1e-8, what="px.mu")
+    assert_close(b.px.Sigma, a.px.Sigma, 1e-8, what="px.Sigma")
+    assert_close(b.A.mu, a.A.mu, 1e-8, what="A.mu")
+    assert_close(b.obs_model.mu, a.obs_model.mu, 1e-8, what="obs.mu")
+    assert_close(b.ELBO().sum(), a.ELBO().sum(), 1e-8, what="ELBO")

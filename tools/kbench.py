@@ -5,6 +5,7 @@ events at the launch, plus the implied fraction of the 8 TB/s HBM peak.  Develop
     python tools/kbench.py niw [--B 1000000] [--reps 30]
 """
 import argparse
+import time
 import os
 import sys
 
@@ -187,6 +188,47 @@ def bench_dmbd(args):
         print(f"dmbd {name}: T={T} S={S} n_obs={n_obs}: {dt_ * 1e3:.1f} ms / VB iteration, ELBO {float(m.ELBO_last):.4e}", flush=True)
 
 
+def bench_lds0(args):
+    """The reference's own LDS example size (T=399, 64 series, hidden 6, obs 6, fp64; reference CPU
+    0.45 s per E-step, 1.7 s per 3 VB iterations): launch-bound on a GPU, so also timed as a HIP graph replay."""
+    from pyvbmp_amd.models import LinearDynamicalSystems
+    T, S, h = 399, 64, 6
+    g = torch.Generator(device="cuda").manual_seed(0)
+    y = torch.randn(T, S, 6, generator=g, device="cuda", dtype=torch.float64).cumsum(0) * 0.05
+    for graphed in (False, True):
+        torch.manual_seed(0)
+        m = LinearDynamicalSystems((6,), h, device="cuda", dtype=torch.float64)
+        m.update(y, iters=4, graphed=graphed)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m.update(y, iters=20, graphed=graphed)
+        torch.cuda.synchronize()
+        dt_ms = (time.perf_counter() - t0) / 20 * 1e3
+        print(f"lds example size (T=399, S=64, h=6, fp64) {'HIP graph' if graphed else 'eager    '}: {dt_ms:.3f} ms per VB "
+              f"iteration, ELBO {float(m.ELBO().sum()):.4f}", flush=True)
+
+
+def bench_gmm0(args):
+    """BASELINE configs[0]: GaussianMixtureModel(4, 2) on 400 two-cluster points, 20 VB iterations: launch-bound, so the
+    iteration is also timed as a HIP graph replay (pyvbmp_amd.graph)."""
+    from pyvbmp_amd.models import GaussianMixtureModel
+    g = torch.Generator(device="cuda").manual_seed(0)
+    X = torch.cat((torch.randn(200, 2, generator=g, device="cuda", dtype=torch.float64) + 2.5,
+                   torch.randn(200, 2, generator=g, device="cuda", dtype=torch.float64) - 2.5))
+    for graphed in (False, True):
+        m = GaussianMixtureModel(4, 2, device="cuda", dtype=torch.float64)
+        m.update(X, iters=5, graphed=graphed)  # builds the graph when asked for
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            m.update(X, iters=20, graphed=graphed)
+        torch.cuda.synchronize()
+        dt_ms = (time.perf_counter() - t0) / reps * 1e3
+        print(f"gmm config0 (K=4, D=2, N=400, fp64) {'HIP graph' if graphed else 'eager    '}: {dt_ms:.3f} ms per 20 "
+              f"iterations ({dt_ms / 20 * 1e3:.0f} us / iteration), ELBO {float(m.ELBO()):.4f}", flush=True)
+
+
 def bench_gmm(args):
     """GMM at scale: fused E-step (K3), weighted moments (K4) and one full VB iteration, N samples, K=4, D=16."""
     from pyvbmp_amd.models import GaussianMixtureModel
@@ -216,4 +258,4 @@ if __name__ == "__main__":
     ap.add_argument("--S", type=int, default=4096)
     args = ap.parse_args()
     for w in args.what:
-        {"niw": bench_niw, "copy": bench_copy, "mnw": bench_mnw, "lds": bench_lds, "dmbd": bench_dmbd, "gmm": bench_gmm}[w](args)
+        {"niw": bench_niw, "copy": bench_copy, "mnw": bench_mnw, "lds": bench_lds, "dmbd": bench_dmbd, "gmm": bench_gmm, "gmm0": bench_gmm0, "lds0": bench_lds0}[w](args)
