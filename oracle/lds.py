@@ -173,10 +173,17 @@ def latent_stats(sm, y, u, r, obs_shape, control_dim, regression_dim, batch_shap
     return out
 
 
-def reduce_stats(st, batch_dim, n_extra_obs):
-    """sum over the sample axes + symmetrise.  ref :135-150 (p=None)"""
+def reduce_stats(st, batch_dim, n_extra_obs, p=None):
+    """(per-series weights p, ref :106-121, then) sum over the sample axes + symmetrise.  ref :135-150"""
     st = dict(st)
     keys = ("SE_x0_x0", "SE_x0", "SE_xpu_xpu", "SE_x_xpu", "SE_x_x", "SE_xr_xr", "SE_y_xr", "SE_y_y", "T", "N")
+    if p is not None:
+        for _ in range(n_extra_obs):
+            p = p.unsqueeze(-1)
+        st["T"], st["N"] = st["T"] * p, st["N"] * p
+        pm = p.unsqueeze(-1).unsqueeze(-1)
+        for k in keys[:-2]:
+            st[k] = st[k] * pm
     while st["SE_x_x"].ndim > batch_dim + n_extra_obs + 2:
         for k in keys:
             st[k] = st[k].sum(0)

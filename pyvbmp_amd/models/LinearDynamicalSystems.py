@@ -128,13 +128,7 @@ class LinearDynamicalSystems():
     def ss_update(self, p=None, lr=1.0):
         """statistics (time already integrated) -> sum over samples -> M-step of x0 and A (ref :104-154)"""
         if p is not None:
-            for i in range(len(self.offset)):
-                p = p.unsqueeze(-1)
-            self.T = self.T * p
-            self.N = self.N * p
-            p = p.unsqueeze(-1).unsqueeze(-1)
-            for k in self._STATS:
-                setattr(self, k, getattr(self, k) * p)
+            self.weight_statistics(p)
         while self.SE_x_x.ndim > self.batch_dim + len(self.offset) + 2:
             for k in self._STATS + ("T", "N"):
                 setattr(self, k, getattr(self, k).sum(0))
@@ -144,6 +138,17 @@ class LinearDynamicalSystems():
         self.x0.ss_update(self.SE_x0_x0, self.SE_x0.squeeze(-1), self.N, lr)
         self.A.ss_update(self.SE_xpu_xpu, self.SE_x_xpu, self.SE_x_x, self.T, lr)
         self.set_latent_parms()
+
+    def weight_statistics(self, p):
+        """per-series weights on the statistics of the last E-step (the `p` branch of the reference's ss_update,
+        ref :106-121); separate so that sample-sharded callers can weight, reduce over ranks, then update"""
+        for i in range(len(self.offset)):
+            p = p.unsqueeze(-1)
+        self.T = self.T * p
+        self.N = self.N * p
+        p = p.unsqueeze(-1).unsqueeze(-1)
+        for k in self._STATS:
+            setattr(self, k, getattr(self, k) * p)
 
     def reduce_statistics(self, extra=()):
         """Sample-sharded runs (case 2): sum the local series' statistics, then ONE all-reduce of the

@@ -3,3 +3,4 @@ from .DynamicMarkovBlanketDiscovery import DynamicMarkovBlanketDiscovery
 from .GaussianMixtureModel import GaussianMixtureModel
 from .HMM import HMM
 from .LinearDynamicalSystems import LinearDynamicalSystems
+from .MixtureofLinearDynamicalSystems import MixtureofLinearDynamicalSystems

@@ -157,3 +157,37 @@ def test_dmbd_series_sharded_matches_single(golden):
         assert_close(m.B.mu, ref.B.mu, 1e-8)
         assert_close(m.obs_model.transition.alpha, ref.obs_model.transition.alpha, 1e-8)
         assert_close(m.ELBO_last, ref.ELBO_last, 1e-8)
+
+
+def test_mixture_of_lds_series_sharded_matches_single(golden):
+    """MixtureofLinearDynamicalSystems with the series split over two ranks: the weighted LDS statistics, NA and the
+    evidence cross the ranks in ONE packed all-reduce per iteration; same posterior as the unsharded run"""
+    from pyvbmp_amd.models import MixtureofLinearDynamicalSystems
+    c = golden("mixlds")["mix3_h3_o5"]
+    y = c["y"].to(DEV)  # (T, 6 series, 5)
+
+    def make():
+        m = MixtureofLinearDynamicalSystems(3, (5,), 3, 0, 0, device=DEV, dtype=torch.float64)
+        m.lds.x0.mu = c["init_x0_mu"].to(DEV)
+        m.lds.A.mu = c["init_A_mu"].to(DEV)
+        m.lds.A.invU.gamma.alpha = c["init_A_alpha"].to(DEV)
+        m.lds.A.invU.gamma.beta = c["init_A_beta"].to(DEV)
+        m.lds.obs_model.mu = c["init_obs_mu"].to(DEV)
+        m.lds.set_latent_parms()
+        m.pi.alpha = c["init_pi_alpha"].to(DEV)
+        return m
+
+    def step(m, d):
+        m.lds.reducer = m.reducer  # _run_pair hands the reducer to the model; the statistics live in its LDS
+        m.update(d, None, None, iters=3, verbose=False)
+    ref = make()
+    ref.update(y, None, None, iters=3, verbose=False)
+    assert_close(ref.p, c["it3_p"], 1e-9)
+    models = _run_pair(make, [y[:, :3], y[:, 3:]], step)
+    for m in models:
+        assert m.reducer.calls == 3
+        assert_close(m.lds.A.mu, ref.lds.A.mu, 1e-9)
+        assert_close(m.lds.obs_model.mu, ref.lds.obs_model.mu, 1e-9)
+        assert_close(m.pi.alpha, ref.pi.alpha, 1e-9)
+        assert_close(m.ELBO_last, ref.ELBO_last, 1e-9)
+    assert_close(torch.cat((models[0].p, models[1].p), 0), ref.p, 1e-9)

@@ -106,3 +106,38 @@ def test_lds_default_transition_golden(golden, case):
         assert_close(m.A.invU.gamma.beta, c[pre + "A_beta"], 1e-9)
         assert_close(m.obs_model.mu, c[pre + "obs_mu"], 1e-9)
     assert_close(m.KLqprior(), c["KLqprior"], 1e-9)
+
+
+@pytest.mark.parametrize("case", ["mix3_h3_o5", "mix2_h2_o4_ctrl_reg"])
+def test_mixture_of_lds_golden(golden, case):
+    """MixtureofLinearDynamicalSystems on the device against fixtures captured from the reference"""
+    from pyvbmp_amd.models import MixtureofLinearDynamicalSystems
+    from tests.test_oracle_lds import n_iters
+    c = golden("mixlds")[case]
+    K, h = int(c["K"]), int(c["hidden"])
+    obs_shape = tuple(int(v) for v in c["obs_shape"])
+    m = MixtureofLinearDynamicalSystems(K, obs_shape, h, int(c["control"]), int(c["regression"]), device=DEV,
+                                        dtype=torch.float64)
+    m.lds.x0.mu = c["init_x0_mu"].to(DEV)
+    m.lds.A.mu = c["init_A_mu"].to(DEV)
+    m.lds.A.invU.gamma.alpha = c["init_A_alpha"].to(DEV)
+    m.lds.A.invU.gamma.beta = c["init_A_beta"].to(DEV)
+    m.lds.obs_model.mu = c["init_obs_mu"].to(DEV)
+    m.lds.set_latent_parms()
+    m.pi.alpha = c["init_pi_alpha"].to(DEV)  # the constructor draws it from the global RNG
+    lr = float(c["lr"])
+    dev = lambda k: c[k].to(DEV) if k in c else None  # noqa: E731
+    for it in range(1, n_iters(c) + 1):
+        pre = f"it{it}_"
+        m.update(dev("y"), dev("u"), dev("r"), iters=1, lr=lr, verbose=False)
+        assert_close(m.p, c[pre + "p"], 1e-9, what=pre + "p")
+        assert_close(m.NA, c[pre + "NA"], 1e-9, what=pre + "NA")
+        assert_close(m.logZ, c[pre + "logZ"], 1e-9, what=pre + "logZ")
+        assert_close(m.pi.alpha, c[pre + "pi_alpha"], 1e-9, what=pre + "alpha")
+        assert_close(m.lds.A.mu, c[pre + "A_mu"], 1e-9, what=pre + "A_mu")
+        assert_close(m.lds.A.invU.gamma.alpha, c[pre + "A_alpha"], 1e-9)
+        assert_close(m.lds.A.invU.gamma.beta, c[pre + "A_beta"], 1e-9)
+        assert_close(m.lds.obs_model.mu, c[pre + "obs_mu"], 1e-9, what=pre + "obs_mu")
+        assert_close(m.lds.x0.mu, c[pre + "x0_mu"], 1e-9, what=pre + "x0_mu")
+    assert_close(m.KLqprior(), c["KLqprior"], 1e-9, what="KL")
+    assert torch.equal(m.assignment().cpu(), c["assignment"])

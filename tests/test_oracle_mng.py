@@ -108,3 +108,50 @@ def test_lds_default_transition_oracle_golden(golden, case):
         assert_close(A["W"]["alpha"], c[pre + "A_alpha"], 1e-9)
         assert_close(A["W"]["beta"], c[pre + "A_beta"], 1e-9)
         assert_close(obs["mu"], c[pre + "obs_mu"], 1e-9)
+
+
+MIXLDS_CASES = ["mix3_h3_o5", "mix2_h2_o4_ctrl_reg"]
+
+
+@pytest.mark.parametrize("case", MIXLDS_CASES)
+def test_mixture_of_lds_oracle_golden(golden, case):
+    """MixtureofLinearDynamicalSystems (ref models/MixtureofLinearDynamicalSystems.py:12-34) restated on the
+    functional LDS oracle: per-series evidences -> responsibilities -> weighted M-step, against reference fixtures."""
+    from oracle import mixture as omix
+    from tests.test_oracle_lds import n_iters
+    c = golden("mixlds")[case]
+    K = int(c["K"])
+    c = dict(c)
+    c["batch_shape"] = torch.tensor([K])
+    x0, A, obs, h, obs_shape, batch, cd, rd = ldsg_states(c)
+    nx = len(obs_shape) - 1
+    lr = float(c["lr"])
+    alpha_0 = torch.full((K,), 0.5, dtype=torch.float64)
+    alpha = c["init_pi_alpha"]
+    y, u, r = olds.reshape_inputs(c["y"], c.get("u"), c.get("r"), obs_shape, cd, rd, batch, True)
+    for it in range(1, n_iters(c) + 1):
+        pre = f"it{it}_"
+        sm = olds.smoother(olds.latent_parms(A, h), x0, h, y, u, r, obs, nx)
+        st = olds.latent_stats(sm, y, u, r, obs_shape, cd, rd, batch, nx)
+        lz = st["logZ"]
+        while lz.ndim > 2:
+            lz = lz.sum(0)
+        assert_close(lz, c[pre + "lds_logZ"], 1e-9, what=pre + "lds_logZ")
+        log_p = lz + omix.dirichlet_loggeomean(alpha)
+        logZ = torch.logsumexp(log_p, -1)
+        p = torch.exp(log_p - logZ.unsqueeze(-1))
+        assert_close(p, c[pre + "p"], 1e-9, what=pre + "p")
+        assert_close(logZ, c[pre + "logZ"], 1e-9, what=pre + "logZ")
+        NA = p.sum(0)
+        assert_close(NA, c[pre + "NA"], 1e-9, what=pre + "NA")
+        alpha = omix.dirichlet_ss_update(alpha_0, alpha, NA, lr)
+        assert_close(alpha, c[pre + "pi_alpha"], 1e-9, what=pre + "alpha")
+        st = olds.reduce_stats(st, len(batch), nx, p=p)
+        x0 = oniw.niw_ss_update(x0, st["SE_x0_x0"], st["SE_x0"].squeeze(-1), st["N"], lr)
+        A = omnw.mnw_ss_update(A, st["SE_xpu_xpu"], st["SE_x_xpu"], st["SE_x_x"], st["T"], lr)
+        obs = omnw.mnw_ss_update(obs, st["SE_xr_xr"], st["SE_y_xr"], st["SE_y_y"], st["T"], lr)
+        assert_close(A["mu"], c[pre + "A_mu"], 1e-9, what=pre + "A_mu")
+        assert_close(A["W"]["alpha"], c[pre + "A_alpha"], 1e-9)
+        assert_close(A["W"]["beta"], c[pre + "A_beta"], 1e-9)
+        assert_close(obs["mu"], c[pre + "obs_mu"], 1e-9, what=pre + "obs_mu")
+        assert_close(x0["mu"], c[pre + "x0_mu"], 1e-9, what=pre + "x0_mu")

@@ -919,6 +919,59 @@ def gen_dmbd():
 
 GROUPS["dmbd"] = gen_dmbd
 
+# ---------------------------------------------------------------------- mixture of LDS
+def mixlds_case(b, name, K, T, S, obs_shape, hidden, gen, control=0, regression=0, iters=3, lr=1.0):
+    import contextlib
+    import io
+
+    import models  # reference
+    b.begin(name)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = models.MixtureofLinearDynamicalSystems(K, obs_shape, hidden, control, regression)
+    for k, v in (("K", K), ("T", T), ("S", S), ("hidden", hidden), ("control", control), ("regression", regression),
+                 ("lr", lr)):
+        b.put(k, v)
+    b.put("obs_shape", np.array(obs_shape, dtype=np.int64))
+    snap_lds_state_mng(b, m.lds, "init_")
+    b.put("init_pi_alpha", m.pi.alpha)
+    # two families of series (different oscillation frequencies) so that the systems specialise
+    tt = torch.arange(T, dtype=torch.float64).reshape(T, 1, 1)
+    fam = (torch.arange(S) % 2).reshape(1, S, 1).to(torch.float64)
+    lat = torch.cat([torch.sin((0.15 + 0.25 * fam) * tt * (k + 1) + torch.rand(1, S, 1, generator=gen) * 6)
+                     for k in range(hidden)], -1)
+    W = torch.randn(obs_shape + (hidden,), generator=gen)
+    y = (W @ lat.reshape((T, S) + (1,) * (len(obs_shape) - 1) + (hidden, 1))).squeeze(-1)
+    y = y + 0.1 * torch.randn(y.shape, generator=gen)
+    u = torch.randn(T, S, control, generator=gen) if control else None
+    r = torch.randn((T, S) + obs_shape[:-1] + (regression,), generator=gen) if regression else None
+    b.put("y", y)
+    b.put("u", u)
+    b.put("r", r)
+    for it in range(1, iters + 1):
+        with contextlib.redirect_stdout(io.StringIO()):
+            m.update(y, u, r, iters=1, lr=lr)
+        pre = f"it{it}_"
+        b.put(pre + "p", m.p)
+        b.put(pre + "NA", m.NA)
+        b.put(pre + "logZ", m.logZ)
+        b.put(pre + "lds_logZ", m.lds.logZ)
+        b.put(pre + "pi_alpha", m.pi.alpha)
+        snap_lds_state_mng(b, m.lds, pre)
+    b.put("KLqprior", m.KLqprior())
+    b.put("assignment", m.assignment())
+
+
+def gen_mixlds():
+    b = Book()
+    gen = torch.Generator().manual_seed(4242)
+    torch.manual_seed(23)
+    mixlds_case(b, "mix3_h3_o5", 3, 20, 6, (5,), 3, gen, iters=3)
+    mixlds_case(b, "mix2_h2_o4_ctrl_reg", 2, 16, 5, (4,), 2, gen, control=2, regression=1, iters=2, lr=0.6)
+    b.save("mixlds")
+
+
+GROUPS["mixlds"] = gen_mixlds
+
 
 if __name__ == "__main__":
     want = sys.argv[1:] or list(GROUPS)
