@@ -1,0 +1,192 @@
+"""Mixture of linear transforms: `dim` MatrixNormalWishart (or MatrixNormalGamma) experts gated by a Dirichlet
+(surface of the reference's transforms/MixtureofLinearTransforms.py:10-215; SURVEY.md 8(f) row 4, the part that
+needs no new arithmetic -- the logistic-regression gate of dMixtureofLinearTransforms is not on this path).
+
+Everything heavy is the MatrixNormalWishart path already built: the experts are ONE transform with batch_shape
+(..., dim); the E-step is its joint quadratic form over z = [x; y] for every (sample, expert) followed by the
+softmax over experts (K3a + an elementwise pass), and the M-step is
+`W.raw_update / W.update` with the responsibilities as weights (K4 moments of z, K5b covariance sums, K1/K2a
+update).
+"""
+import torch
+
+from ..dists.Dirichlet import Dirichlet
+from ..dists.MultivariateNormal_vector_format import MultivariateNormal_vector_format
+from .MatrixNormalGamma import MatrixNormalGamma
+from .MatrixNormalWishart import MatrixNormalWishart
+
+
+class MixtureofLinearTransforms():
+    def __init__(self, n, p, dim, batch_shape=(), pad_X=True, type='Wishart', device=None, dtype=None):
+        self.n, self.p, self.dim = n, p, dim  # dim = number of experts
+        self.event_dim = 1
+        self.event_shape = (dim,)
+        self.batch_shape = tuple(batch_shape)
+        self.batch_dim = len(self.batch_shape)
+        self.padX = pad_X
+        if type == 'Wishart':
+            cls = MatrixNormalWishart
+        elif type == 'Gamma':
+            cls = MatrixNormalGamma
+        else:
+            raise ValueError('type must be either Wishart (default) or Gamma')
+        self.W = cls(event_shape=(n, p), batch_shape=self.batch_shape + (dim,), scale=1.0 / dim ** (1.0 / n),
+                     pad_X=pad_X, device=device, dtype=dtype)
+        self.device, self.dtype = self.W.device, self.W.dtype
+        self.pi = Dirichlet(event_shape=(dim,), batch_shape=self.batch_shape, device=self.device, dtype=self.dtype)
+        self.KL_last = self.KLqprior()
+        self.ELBO_last = torch.full((), -torch.inf, device=self.device, dtype=self.dtype)
+
+    # ------------------------------------------------------------------ E-step
+    def _normalise(self, log_p):
+        """responsibilities and per-sample evidence from unnormalised log-probabilities (ref :36-43)"""
+        logZ = torch.logsumexp(log_p, -1, keepdim=True)
+        self.p = torch.exp(log_p - logZ)
+        self.logZ = logZ.squeeze(-1)
+
+    def update_assignments(self, X, Y):
+        # W.Elog_like is one K3a launch: the joint quadratic form of z = [x; y] for every (sample, expert)
+        self._normalise(self.W.Elog_like(X.unsqueeze(-3), Y.unsqueeze(-3)) + self.pi.loggeomean())
+
+    def update_assignments_given_pX_pY(self, pX, pY):
+        self._normalise(self.W.Elog_like_given_pX_pY(pX.unsqueeze(-3), pY.unsqueeze(-3)) + self.pi.loggeomean())
+
+    def Elog_like(self, X, Y):
+        self.update_assignments(X, Y)
+        ELL = self.logZ
+        for i in range(self.event_dim - 1):
+            ELL = ELL.sum(-1)
+        return ELL
+
+    def Elog_like_given_pX_pY(self, pX, pY):
+        ELL = (self.W.Elog_like_given_pX_pY(pX.unsqueeze(-3), pY.unsqueeze(-3)) * self.p).sum(-1)
+        for i in range(self.event_dim - 1):
+            ELL = ELL.sum(-1)
+        return ELL
+
+    # ------------------------------------------------------------------ VB iterations
+    def raw_update(self, X, Y, iters=1, lr=1.0, verbose=False):
+        for i in range(iters):
+            self.update_assignments(X, Y)
+            ELBO = self.ELBO()
+            self.pi.ss_update(self.p.sum(0), lr=lr)
+            self.W.raw_update(X.unsqueeze(-3), Y.unsqueeze(-3), p=self.p, lr=lr)
+            if verbose:
+                print('MixLinearTransform: Percent Change in ELBO = ',
+                      ((ELBO - self.ELBO_last) / self.ELBO_last.abs()).data * 100)
+            self.ELBO_last = ELBO
+
+    def update(self, pX, pY, iters=1, lr=1, verbose=False):
+        for i in range(iters):
+            self.update_assignments_given_pX_pY(pX, pY)
+            ELBO = self.ELBO()
+            self.pi.ss_update(self.p.sum(0), lr=lr)
+            self.W.update(pX.unsqueeze(-3), pY.unsqueeze(-3), p=self.p, lr=lr)
+            if verbose:
+                print('MixLinearTransform: Percent Change in ELBO = ',
+                      ((ELBO - self.ELBO_last) / self.ELBO_last.abs()).data * 100)
+            self.ELBO_last = ELBO
+
+    def predict(self, X):
+        """moment-matched Gaussian over y and the gate probabilities given x (ref :91-109)"""
+        pY, Res = self.W.predict(X.unsqueeze(-3))
+        log_p = Res + self.pi.loggeomean()
+        p = torch.softmax(log_p, -1)
+        pw = p.unsqueeze(-1).unsqueeze(-1)
+        m = pY.mean()
+        mu = (m * pw).sum(-3)
+        Sigma = ((pY.ESigma() + m @ m.transpose(-2, -1)) * pw).sum(-3) - mu @ mu.transpose(-2, -1)
+        return MultivariateNormal_vector_format(mu=mu, Sigma=Sigma), p
+
+    def forward(self, pX):
+        pass
+
+    def Elog_like_X(self, Y):
+        pass
+
+    def backward(self, pY):
+        pass
+
+    def KLqprior(self):
+        return self.pi.KLqprior() + self.W.KLqprior().sum(-1)
+
+    def ELBO(self):
+        logZ = self.logZ.sum(0)
+        while logZ.ndim > self.batch_dim:
+            logZ = logZ.sum(0)
+        return logZ - self.KLqprior()
+
+    def assignment_pr(self):
+        return self.p
+
+    def assignment(self):
+        return self.p.argmax(-1)
+
+    def mean(self):
+        return self.p
+
+    # ------------------------------------------------------------------ responsibility-weighted expectations
+    def event_average(self, A):
+        """A: mixture batch + (dim,) + W.event_shape -> sample + W.event_shape, averaged with self.p (ref :141-149)"""
+        p = self.p.reshape(tuple(self.p.shape) + (1,) * self.W.event_dim)
+        out = A * p
+        for i in range(self.event_dim):
+            out = out.sum(-self.W.event_dim - 1)
+        return out
+
+    def average(self, A):
+        out = self.p * A
+        for i in range(self.event_dim):
+            out = out.sum(-1)
+        return out
+
+    def EinvUX(self):
+        return self.event_average(self.W.EinvUX())
+
+    def EXTinvU(self):
+        return self.event_average(self.W.EXTinvU())
+
+    def EXTAX(self, A):
+        return self.event_average(self.W.EXTAX(A))
+
+    def EXAXT(self, A):
+        return self.event_average(self.W.EXAXT(A))
+
+    def EXTinvUX(self):
+        return self.event_average(self.W.EXTinvUX())
+
+    def EXinvVXT(self):
+        return self.event_average(self.W.EXinvVXT())
+
+    def EXmMUTinvUXmMU(self):
+        return self.event_average(self.W.EXmMUTinvUXmMU())
+
+    def EXmMUinvVXmMUT(self):
+        return self.event_average(self.W.EXmMUinvVXmMUT())
+
+    def EXTX(self):
+        return self.event_average(self.W.EXTX())
+
+    def EXXT(self):
+        return self.event_average(self.W.EXXT())
+
+    def EinvSigma(self):
+        return self.event_average(self.W.EinvSigma())
+
+    def ESigma(self):
+        return self.event_average(self.W.ESigma())
+
+    def ElogdetinvU(self):
+        return self.average(self.W.invU.ElogdetinvSigma())
+
+    def ElogdetinvSigma(self):
+        return self.average(self.W.ElogdetinvSigma())
+
+    def weights(self):
+        return self.W.mu[..., :-1] if self.padX else self.W.mu
+
+    def bias(self):
+        return self.W.mu[..., -1] if self.padX else None
+
+    def means(self):
+        return self.W.mu

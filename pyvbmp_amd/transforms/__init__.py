@@ -2,3 +2,4 @@
 (transforms/__init__.py:1-13)."""
 from .MatrixNormalGamma import MatrixNormalGamma
 from .MatrixNormalWishart import MatrixNormalWishart
+from .MixtureofLinearTransforms import MixtureofLinearTransforms

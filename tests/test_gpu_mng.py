@@ -141,3 +141,51 @@ def test_mixture_of_lds_golden(golden, case):
         assert_close(m.lds.x0.mu, c[pre + "x0_mu"], 1e-9, what=pre + "x0_mu")
     assert_close(m.KLqprior(), c["KLqprior"], 1e-9, what="KL")
     assert torch.equal(m.assignment().cpu(), c["assignment"])
+
+
+@pytest.mark.parametrize("case", ["mixlt_w_n3_p4_k3", "mixlt_w_nopad_lr", "mixlt_g_n3_p2_k2"])
+def test_mixture_of_linear_transforms_golden(golden, case):
+    """MixtureofLinearTransforms on the device against fixtures captured from the reference:
+    raw_update iterations, predict, responsibility-weighted expectations, update(pX, pY)"""
+    from pyvbmp_amd.dists import MultivariateNormal_vector_format as VF
+    from pyvbmp_amd.transforms import MixtureofLinearTransforms
+    from tests.test_oracle_lds import n_iters
+    c = golden("mixlt")[case]
+    n, p, dim = int(c["n"]), int(c["p"]), int(c["dim"])
+    m = MixtureofLinearTransforms(n, p, dim, pad_X=bool(int(c["pad_X"])), type='Gamma' if int(c["gamma"]) else 'Wishart',
+                                  device=DEV, dtype=torch.float64)
+    m.W.mu = c["init_W_mu"].to(DEV)
+    m.pi.alpha = c["init_pi_alpha"].to(DEV)
+    if int(c["gamma"]):
+        m.W.invU.gamma.alpha = c["init_W_alpha"].to(DEV)
+        m.W.invU.gamma.beta = c["init_W_beta"].to(DEV)
+    lr = float(c["lr"])
+    X, Y = c["X"].to(DEV), c["Y"].to(DEV)
+    for it in range(1, n_iters(c) + 1):
+        pre = f"it{it}_"
+        m.raw_update(X, Y, iters=1, lr=lr)
+        assert_close(m.p, c[pre + "p"], 1e-9, what=pre + "p")
+        assert_close(m.logZ, c[pre + "logZ"], 1e-9, what=pre + "logZ")
+        assert_close(m.ELBO_last, c[pre + "ELBO"], 1e-9, what=pre + "ELBO")
+        assert_close(m.pi.alpha, c[pre + "pi_alpha"], 1e-9, what=pre + "alpha")
+        assert_close(m.W.mu, c[pre + "W_mu"], 1e-9, what=pre + "W_mu")
+        assert_close(m.W.invV, c[pre + "W_invV"], 1e-9, what=pre + "W_invV")
+        if int(c["gamma"]):
+            assert_close(m.W.invU.gamma.alpha, c[pre + "W_alpha"], 1e-9)
+            assert_close(m.W.invU.gamma.beta, c[pre + "W_beta"], 1e-9)
+        else:
+            assert_close(m.W.invU.invU, c[pre + "W_invU"], 1e-9)
+            assert_close(m.W.invU.nu, c[pre + "W_nu"], 1e-9)
+    assert_close(m.KLqprior(), c["KLqprior"], 1e-9, what="KL")
+    pY, pr = m.predict(X[:7])
+    assert_close(pr, c["pred_p"], 1e-9, what="pred p")
+    assert_close(pY.mean(), c["pred_mu"], 1e-9, what="pred mu")
+    assert_close(pY.ESigma(), c["pred_Sigma"], 1e-9, what="pred Sigma")
+    for f in ("EinvUX", "EXTinvUX", "EinvSigma", "ElogdetinvSigma"):
+        assert_close(getattr(m, f)(), c[f], 1e-9, what=f)
+    m.update(VF(mu=X, Sigma=c["upd_SigX"].to(DEV)), VF(mu=Y, Sigma=c["upd_SigY"].to(DEV)), iters=1, lr=lr)
+    assert_close(m.p, c["upd_p"], 1e-9, what="upd p")
+    assert_close(m.logZ, c["upd_logZ"], 1e-9, what="upd logZ")
+    assert_close(m.ELBO_last, c["upd_ELBO"], 1e-9, what="upd ELBO")
+    assert_close(m.W.mu, c["upd_W_mu"], 1e-9, what="upd W_mu")
+    assert_close(m.pi.alpha, c["upd_pi_alpha"], 1e-9, what="upd alpha")

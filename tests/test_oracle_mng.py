@@ -155,3 +155,80 @@ def test_mixture_of_lds_oracle_golden(golden, case):
         assert_close(A["W"]["beta"], c[pre + "A_beta"], 1e-9)
         assert_close(obs["mu"], c[pre + "obs_mu"], 1e-9, what=pre + "obs_mu")
         assert_close(x0["mu"], c[pre + "x0_mu"], 1e-9, what=pre + "x0_mu")
+
+
+MIXLT_CASES = ["mixlt_w_n3_p4_k3", "mixlt_w_nopad_lr", "mixlt_g_n3_p2_k2"]
+
+
+def mixlt_state(c):
+    n, p, dim = int(c["n"]), int(c["p"]), int(c["dim"])
+    pad = bool(int(c["pad_X"]))
+    scale = 1.0 / dim ** (1.0 / n)
+    if int(c["gamma"]):
+        st = omnw.mng_new((n, p), (dim,), mu_init=c["init_W_mu"], alpha_init=c["init_W_alpha"],
+                          beta_init=c["init_W_beta"], scale=scale, pad_X=pad)
+    else:
+        st = omnw.mnw_new((n, p), (dim,), mu_init=c["init_W_mu"], scale=scale, pad_X=pad)
+    return st, n, p, dim
+
+
+@pytest.mark.parametrize("case", MIXLT_CASES)
+def test_mixture_of_linear_transforms_oracle_golden(golden, case):
+    """MixtureofLinearTransforms.raw_update / update / predict (ref transforms/MixtureofLinearTransforms.py:35-109)
+    restated on the MNW oracle, against reference fixtures"""
+    from oracle import mixture as omix
+    from tests.test_oracle_lds import n_iters
+    c = golden("mixlt")[case]
+    st, n, p, dim = mixlt_state(c)
+    lr = float(c["lr"])
+    alpha_0 = torch.full((dim,), 0.5, dtype=torch.float64)
+    alpha = c["init_pi_alpha"]
+    X, Y = c["X"], c["Y"]
+    Xe, Ye = X.unsqueeze(-3), Y.unsqueeze(-3)
+
+    def estep(log_like):
+        log_p = log_like + omix.dirichlet_loggeomean(alpha)
+        logZ = torch.logsumexp(log_p, -1)
+        return torch.exp(log_p - logZ.unsqueeze(-1)), logZ
+
+    def elbo(logZ):
+        return logZ.sum(0) - (omix.dirichlet_kl(alpha_0, alpha) + omnw.mnw_kl(st).sum(-1))
+    for it in range(1, n_iters(c) + 1):
+        pre = f"it{it}_"
+        pr, logZ = estep(omnw.mnw_elog_like(st, Xe, Ye))
+        assert_close(pr, c[pre + "p"], 1e-9, what=pre + "p")
+        assert_close(logZ, c[pre + "logZ"], 1e-9, what=pre + "logZ")
+        assert_close(elbo(logZ), c[pre + "ELBO"], 1e-9, what=pre + "ELBO")
+        alpha = omix.dirichlet_ss_update(alpha_0, alpha, pr.sum(0), lr)
+        N = X.shape[0]
+        st = omnw.mnw_ss_update(st, *omnw.mnw_moments_data(st, Xe.expand(N, dim, p, 1), Ye, pr), lr=lr)
+        assert_close(alpha, c[pre + "pi_alpha"], 1e-9, what=pre + "alpha")
+        assert_close(st["mu"], c[pre + "W_mu"], 1e-9, what=pre + "W_mu")
+        assert_close(st["invV"], c[pre + "W_invV"], 1e-9, what=pre + "W_invV")
+    assert_close(omix.dirichlet_kl(alpha_0, alpha) + omnw.mnw_kl(st).sum(-1), c["KLqprior"], 1e-9, what="KL")
+    # predict: moment-matched mixture of the experts' predictive Gaussians
+    P, eta, res = omnw.mnw_predict(st, X[:7].unsqueeze(-3))
+    if int(c["gamma"]):  # MatrixNormalGamma.predict hands back the un-normalised residual (ref MatrixNormalGamma.py:367-376)
+        res = res + omnw._res_nat(P, eta)
+    pg = torch.softmax(res + omix.dirichlet_loggeomean(alpha), -1)
+    Sig = torch.linalg.inv(P).expand(7, dim, n, n)
+    m = Sig @ eta
+    pw = pg.unsqueeze(-1).unsqueeze(-1)
+    mu = (m * pw).sum(-3)
+    assert_close(pg, c["pred_p"], 1e-9, what="pred p")
+    assert_close(mu, c["pred_mu"], 1e-9, what="pred mu")
+    assert_close(((Sig + m @ m.transpose(-2, -1)) * pw).sum(-3) - mu @ mu.transpose(-2, -1), c["pred_Sigma"], 1e-9)
+    # update(pX, pY): expected log-likelihood E-step, moments from distributions
+    EX, EY = Xe, Ye
+    EXXT = (c["upd_SigX"] + X @ X.transpose(-2, -1)).unsqueeze(-3)
+    EYYT = (c["upd_SigY"] + Y @ Y.transpose(-2, -1)).unsqueeze(-3)
+    pr, logZ = estep(omnw.mnw_elog_like_dists(st, EX, EXXT, EY, EYYT))
+    assert_close(pr, c["upd_p"], 1e-9, what="upd p")
+    assert_close(logZ, c["upd_logZ"], 1e-9, what="upd logZ")
+    assert_close(elbo(logZ), c["upd_ELBO"], 1e-9, what="upd ELBO")
+    alpha = omix.dirichlet_ss_update(alpha_0, alpha, pr.sum(0), lr)
+    N = X.shape[0]
+    st = omnw.mnw_ss_update(st, *omnw.mnw_moments_dists(st, EX.expand(N, dim, p, 1), EXXT.expand(N, dim, p, p), EY, EYYT,
+                                                         pr), lr=lr)
+    assert_close(st["mu"], c["upd_W_mu"], 1e-9, what="upd W_mu")
+    assert_close(alpha, c["upd_pi_alpha"], 1e-9, what="upd alpha")

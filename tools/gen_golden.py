@@ -972,6 +972,83 @@ def gen_mixlds():
 
 GROUPS["mixlds"] = gen_mixlds
 
+# ---------------------------------------------------------------------- mixture of linear transforms
+def mixlt_case(b, name, n, p, dim, N, gen, pad_X=True, kind='Wishart', iters=3, lr=1.0):
+    import contextlib
+    import io
+
+    import transforms  # reference
+    from dists import MultivariateNormal_vector_format as VF
+    b.begin(name)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = transforms.MixtureofLinearTransforms(n, p, dim, pad_X=pad_X, type=kind)
+    for k, v in (("n", n), ("p", p), ("dim", dim), ("N", N), ("pad_X", int(pad_X)), ("lr", lr),
+                 ("gamma", int(kind == 'Gamma'))):
+        b.put(k, v)
+    b.put("init_W_mu", m.W.mu)
+    b.put("init_pi_alpha", m.pi.alpha)
+    if kind == 'Gamma':
+        b.put("init_W_alpha", m.W.invU.gamma.alpha)
+        b.put("init_W_beta", m.W.invU.gamma.beta)
+    # piecewise-linear data: each sample follows one of `dim` random linear maps
+    X = torch.randn(N, p, 1, generator=gen)
+    Ws = torch.randn(dim, n, p, generator=gen)
+    z = torch.randint(dim, (N,), generator=gen)
+    Y = Ws[z] @ X + 0.5 * torch.randn(dim, n, 1, generator=gen)[z] + 0.1 * torch.randn(N, n, 1, generator=gen)
+    b.put("X", X)
+    b.put("Y", Y)
+    for it in range(1, iters + 1):
+        m.raw_update(X, Y, iters=1, lr=lr)
+        pre = f"it{it}_"
+        b.put(pre + "p", m.p)
+        b.put(pre + "logZ", m.logZ)
+        b.put(pre + "ELBO", m.ELBO_last)
+        b.put(pre + "pi_alpha", m.pi.alpha)
+        b.put(pre + "W_mu", m.W.mu)
+        b.put(pre + "W_invV", m.W.invV)
+        if kind == 'Gamma':
+            b.put(pre + "W_alpha", m.W.invU.gamma.alpha)
+            b.put(pre + "W_beta", m.W.invU.gamma.beta)
+        else:
+            b.put(pre + "W_invU", m.W.invU.invU)
+            b.put(pre + "W_nu", m.W.invU.nu)
+    b.put("KLqprior", m.KLqprior())
+    pY, pr = m.predict(X[:7])
+    b.put("pred_mu", pY.mean())
+    b.put("pred_Sigma", pY.ESigma())
+    b.put("pred_p", pr)
+    b.put("EinvUX", m.EinvUX())
+    b.put("EXTinvUX", m.EXTinvUX())
+    b.put("EinvSigma", m.EinvSigma())
+    b.put("ElogdetinvSigma", m.ElogdetinvSigma())
+    # distributions in: update(pX, pY)
+    A = torch.randn(N, p, p + 2, generator=gen)
+    SigX = A @ A.transpose(-2, -1) / (p + 2) * 0.05
+    pX = VF(mu=X, Sigma=SigX)
+    Bm = torch.randn(N, n, n + 2, generator=gen)
+    pYd = VF(mu=Y, Sigma=Bm @ Bm.transpose(-2, -1) / (n + 2) * 0.05)
+    b.put("upd_SigX", SigX)
+    b.put("upd_SigY", pYd.Sigma)
+    m.update(pX, pYd, iters=1, lr=lr)
+    b.put("upd_p", m.p)
+    b.put("upd_logZ", m.logZ)
+    b.put("upd_W_mu", m.W.mu)
+    b.put("upd_pi_alpha", m.pi.alpha)
+    b.put("upd_ELBO", m.ELBO_last)
+
+
+def gen_mixlt():
+    b = Book()
+    gen = torch.Generator().manual_seed(777)
+    torch.manual_seed(31)
+    mixlt_case(b, "mixlt_w_n3_p4_k3", 3, 4, 3, 60, gen)
+    mixlt_case(b, "mixlt_w_nopad_lr", 2, 3, 4, 50, gen, pad_X=False, iters=2, lr=0.7)
+    mixlt_case(b, "mixlt_g_n3_p2_k2", 3, 2, 2, 40, gen, kind='Gamma', iters=2)
+    b.save("mixlt")
+
+
+GROUPS["mixlt"] = gen_mixlt
+
 
 if __name__ == "__main__":
     want = sys.argv[1:] or list(GROUPS)

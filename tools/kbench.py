@@ -208,6 +208,25 @@ def bench_lds0(args):
               f"iteration, ELBO {float(m.ELBO().sum()):.4f}", flush=True)
 
 
+def bench_mixlt(args):
+    """Mixture of linear transforms at scale: N=1e6 samples, 8 experts, n=p=8 (+bias): the E-step is
+    the K3a quadratic form of z=[x;y] on the matrix cores, the M-step K4 moments with 8 weight columns."""
+    from pyvbmp_amd.transforms import MixtureofLinearTransforms
+    N, n, p, K = 1_000_000, 8, 8, 8
+    for dt in (torch.float64, torch.float32):
+        g = torch.Generator(device="cuda").manual_seed(0)
+        X = torch.randn(N, p, 1, generator=g, device="cuda", dtype=dt)
+        Ws = torch.randn(K, n, p, generator=g, device="cuda", dtype=dt)
+        z = torch.randint(K, (N,), generator=g, device="cuda")
+        Y = Ws[z] @ X + 0.1 * torch.randn(N, n, 1, generator=g, device="cuda", dtype=dt)
+        m = MixtureofLinearTransforms(n, p, K, device="cuda", dtype=dt)
+        m.raw_update(X, Y, iters=2)
+        t_e = _time_call(lambda: m.update_assignments(X, Y), reps=10)
+        t_i = _time_call(lambda: m.raw_update(X, Y, iters=1), reps=10)
+        print(f"mixture of linear transforms {str(dt)[6:]} N={N} n=p=8 experts=8: E-step {t_e:.3f} ms, full VB iteration "
+              f"{t_i:.3f} ms -> {N / t_i * 1e3:.3e} samples/s", flush=True)
+
+
 def bench_gmm0(args):
     """BASELINE configs[0]: GaussianMixtureModel(4, 2) on 400 two-cluster points, 20 VB iterations: launch-bound, so the
     iteration is also timed as a HIP graph replay (pyvbmp_amd.graph)."""
@@ -258,4 +277,4 @@ if __name__ == "__main__":
     ap.add_argument("--S", type=int, default=4096)
     args = ap.parse_args()
     for w in args.what:
-        {"niw": bench_niw, "copy": bench_copy, "mnw": bench_mnw, "lds": bench_lds, "dmbd": bench_dmbd, "gmm": bench_gmm, "gmm0": bench_gmm0, "lds0": bench_lds0}[w](args)
+        {"niw": bench_niw, "copy": bench_copy, "mnw": bench_mnw, "lds": bench_lds, "dmbd": bench_dmbd, "gmm": bench_gmm, "gmm0": bench_gmm0, "lds0": bench_lds0, "mixlt": bench_mixlt}[w](args)
