@@ -65,8 +65,9 @@ def state_tensors(model):
 class GraphedStep():
     """graph = GraphedStep(model, lambda: model.update(X, iters=1)); graph.run(n) == n eager iterations."""
 
-    def __init__(self, model, step, warmup=2):
-        self.model, self.step = model, step
+    def __init__(self, model, step, warmup=2, post=None):
+        """post: optional eager epilogue run after every iteration (bookkeeping whose shapes grow, e.g. an ELBO trace)"""
+        self.model, self.step, self.post = model, step, post
         dev = next((_get(o, k).device for (o, k) in state_tensors(model).values()), None)
         assert dev is not None and dev.type == "cuda", "GraphedStep needs a model whose state lives on the GPU"
         self.device = dev
@@ -78,6 +79,8 @@ class GraphedStep():
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 step()
+                if post is not None:
+                    post()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         before = state_tensors(model)
@@ -106,6 +109,8 @@ class GraphedStep():
         self.static = static
         self.iterations = warmup + 1  # the capture pass does not execute; accounted for by the first replay below
         self.graph.replay()
+        if post is not None:
+            post()
 
     def sync_in(self):
         """state that was rebound outside the graph (an eager update in between) goes back into the static buffers"""
@@ -115,7 +120,9 @@ class GraphedStep():
             if old is None or cur is old:
                 continue
             if cur.shape != old.shape or cur.dtype != old.dtype:
-                raise RuntimeError(f"state tensor {'.'.join(map(str, path))} no longer matches the captured graph")
+                # bookkeeping outside the graph (grown by the `post` epilogue) is simply re-pointed
+                self.static[path] = cur
+                continue
             idx = tuple(slice(0, 1) if (st == 0 and sz > 1) else slice(None) for st, sz in zip(old.stride(), old.shape))
             old[idx].copy_(cur[idx])
             _set(o, k, old)
@@ -123,11 +130,13 @@ class GraphedStep():
     def run(self, iters=1):
         for _ in range(iters):
             self.graph.replay()
+            if self.post is not None:
+                self.post()
         self.iterations += iters
         return self
 
 
-def run_iterations(model, step, iters, key, warmup=2):
+def run_iterations(model, step, iters, key, warmup=2, post=None):
     """`iters` VB iterations of `step()` (one iteration per call) through a cached GraphedStep; iterations that the
     construction of the graph already performed (warm-up + first replay) count towards `iters`.  The graph is
     cached on the model under `key` (data pointer / shape / hyper-parameters of the call): a different key builds
@@ -139,9 +148,11 @@ def run_iterations(model, step, iters, key, warmup=2):
         if iters < warmup + 1:
             for _ in range(iters):
                 step()
+                if post is not None:
+                    post()
             return
         cache.clear()  # one graph (and one private memory pool) per model at a time
-        g = cache[key] = GraphedStep(model, step, warmup=warmup)
+        g = cache[key] = GraphedStep(model, step, warmup=warmup, post=post)
         done = warmup + 1
     else:
         g.sync_in()

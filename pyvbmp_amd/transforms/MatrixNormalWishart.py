@@ -144,10 +144,13 @@ class MatrixNormalWishart():
         if self.mask is not None:  # linear constraint on the posterior mean; same mask for the whole batch
             U = ops.spd_inverse(self.invU.EinvSigma())
             Astar = V_new.unsqueeze(-3).unsqueeze(-2) * U.unsqueeze(-2).unsqueeze(-1)
-            off = ~self.mask
-            A = Astar[..., off, :, :][..., :, off]
+            # the unconstrained entries as integer indices, found once per mask: boolean-mask indexing and the error
+            # check of linalg.solve would each force a device->host synchronisation in every update (the CPU could not
+            # run ahead of the GPU, and the iteration could not be captured into a HIP graph)
+            ri, ci = self._unconstrained_entries()
+            A = Astar[..., ri, ci, :, :][..., :, ri, ci]
             gamma = torch.zeros_like(mu)
-            gamma[..., off] = torch.linalg.solve(A, mu[..., off])
+            gamma[..., ri, ci] = torch.linalg.solve_ex(A, mu[..., ri, ci], check_errors=False)[0]
             mu = (mu - U @ gamma @ V_new) * self.mask
 
         if self.fixed_precision is False:
@@ -161,6 +164,14 @@ class MatrixNormalWishart():
         self.V, self.logdetinvV = ops.spd_inv_logdet(self.invV)
         if self.X_mask is not None:
             self.mu = self.mu * self.X_mask
+
+    def _unconstrained_entries(self):
+        """(row, col) index tensors of the entries the mask leaves free; cached per mask tensor"""
+        cache = getattr(self, "_off_cache", None)
+        if cache is None or cache[0] is not self.mask:
+            ri, ci = torch.nonzero(~self.mask, as_tuple=True)
+            self._off_cache = cache = (self.mask, ri, ci)
+        return cache[1], cache[2]
 
     def _moments(self, EX, EY, covX, covY, p):
         """SExx, SEyx, SEyy, N (+ bias augmentation) from means / covariances / responsibilities.

@@ -179,7 +179,6 @@ def bench_dmbd(args):
                                           device="cuda", dtype=torch.float64)
         m.update(y, None, None, iters=1, lr=0.5)
         torch.cuda.synchronize()
-        import time
         t0 = time.perf_counter()
         its = 3
         m.update(y, None, None, iters=its, lr=0.5)
