@@ -4,6 +4,7 @@ from .Delta import Delta
 from .DiagonalWishart import DiagonalWishart
 from .Dirichlet import Dirichlet
 from .Gamma import Gamma
+from .MVN_ard import MVN_ard
 from .Mixture import Mixture
 from .MultivariateNormal import MultivariateNormal
 from .MultivariateNormal_vector_format import MultivariateNormal_vector_format

@@ -3,3 +3,5 @@
 from .MatrixNormalGamma import MatrixNormalGamma
 from .MatrixNormalWishart import MatrixNormalWishart
 from .MixtureofLinearTransforms import MixtureofLinearTransforms
+from .MultiNomialLogisticRegression import MultiNomialLogisticRegression
+from .dMixtureofLinearTransforms import dMixtureofLinearTransforms

@@ -1049,6 +1049,146 @@ def gen_mixlt():
 
 GROUPS["mixlt"] = gen_mixlt
 
+# ---------------------------------------------------------------------- logistic gate + gated mixture
+def snap_ard(b, q, pre):
+    for f in ("mu", "invSigma", "invSigmamu", "Sigma", "logdetinvSigma"):
+        b.put(pre + f, getattr(q, f))
+    b.put(pre + "alpha", q.alpha.alpha)
+    b.put(pre + "beta", q.alpha.beta)
+
+
+def quiet():
+    import contextlib
+    import io
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+def mnlr_case(b, name, ncls, p, N, gen, pad_X=True, lr=1.0):
+    import transforms  # reference
+    from dists import MultivariateNormal_vector_format as VF
+    b.begin(name)
+    with quiet():
+        m = transforms.MultiNomialLogisticRegression(ncls, p, pad_X=pad_X)
+    for k, v in (("ncls", ncls), ("p", p), ("N", N), ("pad_X", int(pad_X)), ("lr", lr)):
+        b.put(k, v)
+    snap_ard(b, m.beta, "init_")
+    X = torch.randn(N, p, generator=gen)
+    Wt = torch.randn(ncls, p, generator=gen) * 1.5
+    z = torch.distributions.Categorical(logits=X @ Wt.T).sample() if False else (X @ Wt.T + torch.randn(N, ncls, generator=gen)).argmax(-1)
+    Y = torch.nn.functional.one_hot(z, ncls).to(torch.float64)
+    wts = torch.rand(N, generator=gen) + 0.5
+    b.put("X", X)
+    b.put("Y", Y)
+    b.put("w", wts)
+    with quiet():
+        m.raw_update(X, Y, iters=2, lr=lr)
+    snap_ard(b, m.beta, "r1_")
+    with quiet():
+        m.raw_update(X, Y, iters=3, p=wts, lr=lr)
+    snap_ard(b, m.beta, "r2_")
+    b.put("KLqprior", m.KLqprior())
+    b.put("Elog_like", m.Elog_like(X, Y))
+    b.put("log_predict", m.log_predict(X[:9]))
+    b.put("predict", m.predict(X[:9]))
+    b.put("log_predict_1", m.log_predict_1(X[:9]))
+    b.put("log_predict_2", m.log_predict_2(X[:9]))
+    if pad_X:
+        b.put("weights", m.weights())
+    A = torch.randn(N, p, p + 2, generator=gen)
+    SigX = A @ A.transpose(-2, -1) / (p + 2) * 0.1
+    pX = VF(mu=X.unsqueeze(-1), Sigma=SigX)
+    b.put("SigX", SigX)
+    b.put("ELpXpY", m.Elog_like_given_pX_pY(pX, Y))
+    b.put("log_forward", m.log_forward(VF(mu=X[:9].unsqueeze(-1), Sigma=SigX[:9])))
+    pYs = torch.softmax(torch.randn(6, ncls, generator=gen), -1)
+    b.put("bw_pY", pYs)
+    with quiet():
+        px, Res = m.backward(pYs)
+    b.put("bw_invSigma", px.invSigma)
+    b.put("bw_invSigmamu", px.invSigmamu)
+    b.put("bw_mu", px.mu)
+    b.put("bw_Res", Res)
+    with quiet():
+        m.update(pX, Y, iters=2, lr=lr)
+    snap_ard(b, m.beta, "u1_")
+
+
+def dmix_case(b, name, n, p, mix, N, gen, kind='Wishart', iters=3, lr=1.0):
+    import transforms  # reference
+    from dists import MultivariateNormal_vector_format as VF
+    b.begin(name)
+    with quiet():
+        m = transforms.dMixtureofLinearTransforms(n, p, mix, pad_X=True, type=kind)
+    for k, v in (("n", n), ("p", p), ("mix", mix), ("N", N), ("lr", lr), ("gamma", int(kind == 'Gamma'))):
+        b.put(k, v)
+    b.put("init_A_mu", m.A.mu)
+    if kind == 'Gamma':
+        b.put("init_A_alpha", m.A.invU.gamma.alpha)
+        b.put("init_A_beta", m.A.invU.gamma.beta)
+    snap_ard(b, m.pi.beta, "init_pi_")
+    # piecewise-linear map: the active piece depends on the input (what the gate has to learn)
+    X = torch.randn(N, p, generator=gen)
+    z = (X[:, 0] > 0.3).long() + (X[:, 1] > 0.0).long() * (mix > 2)
+    Ws = torch.randn(mix, n, p, generator=gen)
+    Y = (Ws[z] @ X.unsqueeze(-1)).squeeze(-1) + 0.5 * torch.randn(mix, n, generator=gen)[z] + 0.1 * torch.randn(N, n, generator=gen)
+    b.put("X", X)
+    b.put("Y", Y)
+    for it in range(1, iters + 1):
+        with quiet():
+            m.raw_update(X, Y, iters=1, lr=lr)
+        pre = f"it{it}_"
+        b.put(pre + "A_mu", m.A.mu)
+        b.put(pre + "A_invV", m.A.invV)
+        snap_ard(b, m.pi.beta, pre + "pi_")
+    b.put("KLqprior", m.KLqprior())
+    b.put("Elog_like", m.Elog_like(X, Y))
+    pY, pr = m.predict(X[:7])
+    b.put("pred_mu", pY.mean())
+    b.put("pred_Sigma", pY.ESigma())
+    b.put("pred_p", pr)
+    A = torch.randn(N, p, p + 2, generator=gen)
+    SigX = A @ A.transpose(-2, -1) / (p + 2) * 0.05
+    Bm = torch.randn(N, n, n + 2, generator=gen)
+    SigY = Bm @ Bm.transpose(-2, -1) / (n + 2) * 0.05
+    pX, pYd = VF(mu=X.unsqueeze(-1), Sigma=SigX), VF(mu=Y.unsqueeze(-1), Sigma=SigY)
+    b.put("SigX", SigX)
+    b.put("SigY", SigY)
+    b.put("ELpXpY", m.Elog_like_given_pX_pY(pX, pYd))
+    try:  # the reference's forward indexes the expert message as a tuple: fails for Gamma experts (no residual there)
+        with quiet():
+            fw = m.forward(VF(mu=X[:5].unsqueeze(-1), Sigma=SigX[:5]))
+        b.put("fw_mu", fw.mean())
+        b.put("fw_Sigma", fw.ESigma())
+    except TypeError:
+        pass
+    with quiet():
+        px, logZ, pp = m.postdict(Y[:5])
+    b.put("post_invSigma", px.invSigma)
+    b.put("post_invSigmamu", px.invSigmamu)
+    b.put("post_logZ", logZ)
+    b.put("post_p", pp)
+    with quiet():
+        m.update(pX, pYd, iters=1, lr=lr)
+    b.put("upd_logZ", m.logZ)
+    b.put("upd_NA", m.NA)
+    b.put("upd_ELBO", m.ELBO_last)
+    b.put("upd_A_mu", m.A.mu)
+    snap_ard(b, m.pi.beta, "upd_pi_")
+
+
+def gen_dmix():
+    b = Book()
+    gen = torch.Generator().manual_seed(1234)
+    torch.manual_seed(41)
+    mnlr_case(b, "mnlr_c4_p3", 4, 3, 80, gen)
+    mnlr_case(b, "mnlr_c3_p9_lr", 3, 9, 120, gen, lr=0.7)
+    dmix_case(b, "dmix_w_n2_p3_k3", 2, 3, 3, 70, gen)
+    dmix_case(b, "dmix_g_n3_p2_k2", 3, 2, 2, 60, gen, kind='Gamma', iters=2, lr=0.8)
+    b.save("dmix")
+
+
+GROUPS["dmix"] = gen_dmix
+
 
 if __name__ == "__main__":
     want = sys.argv[1:] or list(GROUPS)

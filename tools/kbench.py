@@ -226,6 +226,25 @@ def bench_mixlt(args):
               f"{t_i:.3f} ms -> {N / t_i * 1e3:.3e} samples/s", flush=True)
 
 
+def bench_dmix(args):
+    """The reference's two_moons model class at scale: dMixtureofLinearTransforms (input-dependent Polya-Gamma gate),
+    N=1e6 samples, 8 experts, n=p=8."""
+    from pyvbmp_amd.transforms import dMixtureofLinearTransforms
+    N, n, p, K = 1_000_000, 8, 8, 8
+    for dt in (torch.float64, torch.float32):
+        g = torch.Generator(device="cuda").manual_seed(0)
+        X = torch.randn(N, p, generator=g, device="cuda", dtype=dt)
+        Ws = torch.randn(K, n, p, generator=g, device="cuda", dtype=dt)
+        z = (X[:, :3] > 0).long() @ torch.tensor([1, 2, 4], device="cuda")
+        Y = (Ws[z] @ X.unsqueeze(-1)).squeeze(-1) + 0.1 * torch.randn(N, n, generator=g, device="cuda", dtype=dt)
+        m = dMixtureofLinearTransforms(n, p, K, device="cuda", dtype=dt)
+        m.raw_update(X, Y, iters=2)
+        t_i = _time_call(lambda: m.raw_update(X, Y, iters=1), reps=5)
+        t_g = _time_call(lambda: m.pi.raw_update(X, m.pi.predict(X), iters=2), reps=5)
+        print(f"gated mixture of linear transforms {str(dt)[6:]} N={N} n=p=8 experts=8: full VB iteration {t_i:.3f} ms -> "
+              f"{N / t_i * 1e3:.3e} samples/s (gate predict + 2-sweep update alone {t_g:.3f} ms)", flush=True)
+
+
 def bench_gmm0(args):
     """BASELINE configs[0]: GaussianMixtureModel(4, 2) on 400 two-cluster points, 20 VB iterations: launch-bound, so the
     iteration is also timed as a HIP graph replay (pyvbmp_amd.graph)."""
@@ -276,4 +295,4 @@ if __name__ == "__main__":
     ap.add_argument("--S", type=int, default=4096)
     args = ap.parse_args()
     for w in args.what:
-        {"niw": bench_niw, "copy": bench_copy, "mnw": bench_mnw, "lds": bench_lds, "dmbd": bench_dmbd, "gmm": bench_gmm, "gmm0": bench_gmm0, "lds0": bench_lds0, "mixlt": bench_mixlt}[w](args)
+        {"niw": bench_niw, "copy": bench_copy, "mnw": bench_mnw, "lds": bench_lds, "dmbd": bench_dmbd, "gmm": bench_gmm, "gmm0": bench_gmm0, "lds0": bench_lds0, "mixlt": bench_mixlt, "dmix": bench_dmix}[w](args)
