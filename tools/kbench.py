@@ -235,7 +235,7 @@ def bench_dmix(args):
         g = torch.Generator(device="cuda").manual_seed(0)
         X = torch.randn(N, p, generator=g, device="cuda", dtype=dt)
         Ws = torch.randn(K, n, p, generator=g, device="cuda", dtype=dt)
-        z = (X[:, :3] > 0).long() @ torch.tensor([1, 2, 4], device="cuda")
+        z = ((X[:, :3] > 0).long() * torch.tensor([1, 2, 4], device="cuda")).sum(-1)
         Y = (Ws[z] @ X.unsqueeze(-1)).squeeze(-1) + 0.1 * torch.randn(N, n, generator=g, device="cuda", dtype=dt)
         m = dMixtureofLinearTransforms(n, p, K, device="cuda", dtype=dt)
         m.raw_update(X, Y, iters=2)
