@@ -16,6 +16,8 @@ Restrictions (checked where possible, and capture fails loudly otherwise): the i
 (no `.item()`, no printing of device values), must not change tensor shapes from one iteration to the next, and
 the data tensors passed to it must stay alive and in place.
 """
+import gc
+
 import torch
 
 
@@ -86,6 +88,24 @@ class GraphedStep():
         before = state_tensors(model)
         static = {path: _get(o, k) for path, (o, k) in before.items()}
         self.graph = torch.cuda.CUDAGraph()
+        # No garbage collection while the stream is capturing: models hold their graphs in reference cycles
+        # (model -> cache -> GraphedStep -> step closure -> model), so an older model's graph is destroyed whenever the
+        # cyclic collector happens to run -- and destroying a HIP graph during a capture aborts the process.
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            self._capture(model, step, before, static)
+        finally:
+            if gc_was_on:
+                gc.enable()
+        self.static = static
+        self.iterations = warmup + 1  # the capture pass does not execute; accounted for by the first replay below
+        self.graph.replay()
+        if post is not None:
+            post()
+
+    def _capture(self, model, step, before, static):
         with torch.cuda.graph(self.graph):
             step()
             after = state_tensors(model)
@@ -106,11 +126,6 @@ class GraphedStep():
                             for st, sz in zip(old.stride(), old.shape))
                 old[idx].copy_(new[idx])
                 _set(o, k, old)
-        self.static = static
-        self.iterations = warmup + 1  # the capture pass does not execute; accounted for by the first replay below
-        self.graph.replay()
-        if post is not None:
-            post()
 
     def sync_in(self):
         """state that was rebound outside the graph (an eager update in between) goes back into the static buffers"""
