@@ -17,7 +17,7 @@ from .. import ops
 from ..dists.DiagonalWishart import DiagonalWishart
 from ..dists.MultivariateNormal_vector_format import MultivariateNormal_vector_format
 from ..utils.matrix_utils import matrix_utils
-from .MatrixNormalWishart import MatrixNormalWishart, _LOG2PI, _T, _sq
+from .MatrixNormalWishart import MatrixNormalWishart, _LOG2PI, _T
 
 
 class MatrixNormalGamma(MatrixNormalWishart):

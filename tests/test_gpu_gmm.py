@@ -4,7 +4,7 @@ then K2) through Mixture / GaussianMixtureModel, against golden fixtures capture
 import pytest
 import torch
 
-from tests.helpers import TOL32, TOL64, assert_close
+from tests.helpers import TOL64, assert_close
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from tests.helpers import assert_close
-from tests.test_oracle_lds import LDS_CASES, lds_oracle_states, n_iters
+from tests.test_oracle_lds import LDS_CASES, n_iters
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"

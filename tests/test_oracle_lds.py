@@ -1,7 +1,6 @@
 """Pin the LDS oracle (information filter / smoother E-step + M-step glue) to the reference's golden
 outputs (tests/golden/lds.npz, latent_noise='shared').  CPU only."""
 import pytest
-import torch
 
 from oracle import lds as olds
 from oracle import mnw as omnw
