@@ -245,6 +245,40 @@ def bench_dmix(args):
               f"{N / t_i * 1e3:.3e} samples/s (gate predict + 2-sweep update alone {t_g:.3f} ms)", flush=True)
 
 
+def bench_k1(args):
+    """K1 (batched SPD inverse + logdet) and K2a (Wishart ss_update) at B=1e6: the two other HBM-bound entry points"""
+    from pyvbmp_amd.dists import Wishart
+    B = args.B
+    for dt in (torch.float64, torch.float32):
+        for D in (16, 8, 32):
+            Bd = B if D <= 16 else B // 4
+            SExx, _, N = make_inputs(Bd, D, dt, "cuda")
+            A = SExx + torch.eye(D, device="cuda", dtype=dt)
+            b = A.element_size()
+            ev = []
+            _lib.launch_hooks = (lambda n: ev.append((n, _rec())), lambda n: ev.append((n, _rec())))
+            for _ in range(12):
+                ops.spd_inv_logdet(A)
+            _lib.launch_hooks = None
+            torch.cuda.synchronize()
+            t = sorted(ev[i][1].elapsed_time(ev[i + 1][1]) for i in range(4, len(ev), 2))
+            t1 = t[len(t) // 2]
+            by = (2 * D * D + 1) * b * Bd
+            w = Wishart((D, D), (Bd,), device="cuda", dtype=dt)
+            ev = []
+            _lib.launch_hooks = (lambda n: ev.append((n, _rec())), lambda n: ev.append((n, _rec())))
+            for _ in range(12):
+                w.ss_update(SExx, N, lr=1.0)
+            _lib.launch_hooks = None
+            torch.cuda.synchronize()
+            t = sorted(ev[i][1].elapsed_time(ev[i + 1][1]) for i in range(4, len(ev), 2))
+            t2 = t[len(t) // 2]
+            by2 = (3 * D * D + 3) * b * Bd
+            print(f"K1 spd_inv_logdet {str(dt)[6:]} D={D:2d} B={Bd}: {t1:.4f} ms -> {by / t1 / 1e6:.0f} GB/s ({by / t1 / 1e6 / 80:.1f}%)   "
+                  f"K2a wishart_ss_update: {t2:.4f} ms -> {by2 / t2 / 1e6:.0f} GB/s ({by2 / t2 / 1e6 / 80:.1f}%)", flush=True)
+            del SExx, A, w
+
+
 def bench_gmm0(args):
     """BASELINE configs[0]: GaussianMixtureModel(4, 2) on 400 two-cluster points, 20 VB iterations: launch-bound, so the
     iteration is also timed as a HIP graph replay (pyvbmp_amd.graph)."""
@@ -295,4 +329,4 @@ if __name__ == "__main__":
     ap.add_argument("--S", type=int, default=4096)
     args = ap.parse_args()
     for w in args.what:
-        {"niw": bench_niw, "copy": bench_copy, "mnw": bench_mnw, "lds": bench_lds, "dmbd": bench_dmbd, "gmm": bench_gmm, "gmm0": bench_gmm0, "lds0": bench_lds0, "mixlt": bench_mixlt, "dmix": bench_dmix}[w](args)
+        {"niw": bench_niw, "copy": bench_copy, "mnw": bench_mnw, "lds": bench_lds, "dmbd": bench_dmbd, "gmm": bench_gmm, "gmm0": bench_gmm0, "lds0": bench_lds0, "mixlt": bench_mixlt, "dmix": bench_dmix, "k1": bench_k1}[w](args)
