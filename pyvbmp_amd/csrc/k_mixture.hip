@@ -95,32 +95,36 @@ __global__ __launch_bounds__(256) void k_mixture_estep(const T* __restrict__ X, 
   for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s - threadIdx.x < S; s += (int64_t)gridDim.x * 256) {
     const bool live = s < S;
     T* lrow = stage ? sL + threadIdx.x * KS : p + s * K;
-    T lse = T(0);
+    T lse = T(0), inv = T(0);
     if (live) {
       T x[Dp];
       load_row<T, Dp>(X + s * D, D, x);
-      T mx = -INFINITY, sum = T(0);
+      // one exp per (sample, component): l_k, then e_k = exp(l_k - max), then p_k = e_k / sum  (the fp64 exp is ~50
+      // instructions; an online log-sum-exp plus exp(l - lse) costs 2K + 1 of them per sample, this K + 1)
+      T mx = -INFINITY;
       for (int k = 0; k < K; ++k) {
         const T l = quadform<T, Dp, FULL>(x, D, P + (int64_t)k * D * D, b + (int64_t)k * D, c[k]);
         if (stage) sL[threadIdx.x * KS + k] = l; else lrow[k] = l;
-        if (l > mx) {
-          sum = sum * exp(mx - l) + T(1);
-          mx = l;
-        } else {
-          sum += exp(l - mx);
-        }
+        mx = l > mx ? l : mx;
+      }
+      T sum = T(0);
+      for (int k = 0; k < K; ++k) {
+        const T e = exp((stage ? sL[threadIdx.x * KS + k] : lrow[k]) - mx);
+        if (stage) sL[threadIdx.x * KS + k] = e; else lrow[k] = e;
+        sum += e;
       }
       lse = mx + log(sum);
+      inv = T(1) / sum;
     }
-    // second pass: normalise in place and reduce the responsibilities over the wave, then the block
+    // last pass: normalise in place and reduce the responsibilities over the wave, then the block
     for (int k = 0; k < K; ++k) {
       T v = T(0);
       if (live) {
         if (stage) {
-          v = exp(sL[threadIdx.x * KS + k] - lse);
+          v = sL[threadIdx.x * KS + k] * inv;
           sL[threadIdx.x * KS + k] = v;
         } else {
-          v = exp(lrow[k] - lse);
+          v = lrow[k] * inv;
           lrow[k] = v;
         }
       }
@@ -373,6 +377,90 @@ static int wmom_mfma(const T* X, const T* p, int64_t S, int64_t Bo, int D, T* Nk
   return hipGetLastError() == hipSuccess ? 0 : VBMP_ERR_LAUNCH;
 }
 
+// ------------------------------------------------------------------------------------ K4 for tiny dimensions
+// D <= 4 (the two-moons / two-cluster shapes of BASELINE configs[0]): a 16-wide MFMA tile would be >= 94 % padding,
+// and the job is pure streaming (16 + 8 K bytes per fp64 sample at D = 2).  One lane per sample (grid-stride), the
+// D(D+1)/2 + D + 1 distinct statistics of up to four components in registers, a wave-level butterfly at the end,
+// then one LDS combine per block and one set of global atomics per block.
+template <typename T, int D, int BO>
+__global__ __launch_bounds__(256) void k_wmom_small(const T* __restrict__ X, const T* __restrict__ p, int64_t S,
+                                                     int ps, T* __restrict__ Nk, T* __restrict__ SEx,
+                                                     T* __restrict__ SExx) {
+  constexpr int NS = D * (D + 1) / 2 + D + 1;  // xx^T upper triangle | x | 1
+  T acc[BO][NS];
+#pragma unroll
+  for (int k = 0; k < BO; ++k)
+#pragma unroll
+    for (int e = 0; e < NS; ++e) acc[k][e] = T(0);
+  for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S; s += (int64_t)gridDim.x * 256) {
+    T x[D], w[BO];
+#pragma unroll
+    for (int i = 0; i < D; ++i) x[i] = X[s * D + i];
+#pragma unroll
+    for (int k = 0; k < BO; ++k) w[k] = p ? p[s * ps + k] : T(1);
+#pragma unroll
+    for (int k = 0; k < BO; ++k) {
+      int e = 0;
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        const T wx = w[k] * x[i];
+#pragma unroll
+        for (int j = i; j < D; ++j) acc[k][e++] = xfma(wx, x[j], acc[k][e]);
+        acc[k][D * (D + 1) / 2 + i] += wx;
+      }
+      acc[k][NS - 1] += w[k];
+    }
+  }
+  __shared__ T red[BO * NS];
+  for (int e = threadIdx.x; e < BO * NS; e += 256) red[e] = T(0);
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < BO; ++k)
+#pragma unroll
+    for (int e = 0; e < NS; ++e) {
+      T v = acc[k][e];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) atomicAdd(&red[k * NS + e], v);
+    }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < BO * NS; idx += 256) {
+    const int k = idx / NS, e = idx - k * NS;
+    const T v = red[idx];
+    if (e == NS - 1) {
+      atomicAdd(&Nk[k], v);
+    } else if (e >= D * (D + 1) / 2) {
+      atomicAdd(&SEx[k * D + (e - D * (D + 1) / 2)], v);
+    } else {
+      int i = 0, r = e;  // e -> (i, j) of the upper triangle, row-major
+      while (r >= D - i) {
+        r -= D - i;
+        ++i;
+      }
+      const int j = i + r;
+      atomicAdd(&SExx[(k * D + i) * D + j], v);
+      if (j != i) atomicAdd(&SExx[(k * D + j) * D + i], v);
+    }
+  }
+}
+
+template <typename T, int D>
+static int wmom_small(const T* X, const T* p, int64_t S, int64_t Bo, T* Nk, T* SEx, T* SExx, hipStream_t st) {
+  int64_t blocks = (S + 255) / 256;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  const dim3 g((unsigned)blocks), b(256);
+#define VBMP_WS(BO)                                                                                                   \
+  hipLaunchKernelGGL((k_wmom_small<T, D, BO>), g, b, 0, st, X, p ? p + k0 : p, S, (int)Bo, Nk + k0, SEx + k0 * D,      \
+                     SExx + k0 * D * D)
+  for (int64_t k0 = 0; k0 < Bo; k0 += 4) {
+    const int64_t nb = Bo - k0 < 4 ? Bo - k0 : 4;
+    if (nb == 1) VBMP_WS(1); else if (nb == 2) VBMP_WS(2); else if (nb == 3) VBMP_WS(3); else VBMP_WS(4);
+  }
+#undef VBMP_WS
+  return hipGetLastError() == hipSuccess ? 0 : VBMP_ERR_LAUNCH;
+}
+
 // ------------------------------------------------------------------------------------ K3a / K3 on the matrix cores
 // out[s,bo,bi] = -1/2 x'Px + x'b + c for 16 samples at a time:  (P x_j)_i = sum_f P[i][f] x_j[f]  is the 16x16x4 MFMA
 // with A = P (rows i = feature out, LDS resident in operand order), B = X^T (k = feature in, column j = sample), so
@@ -514,12 +602,17 @@ __global__ __launch_bounds__(256) void k_estep_softmax(T* __restrict__ p, int64_
       for (int k = 0; k < K; ++k) mx = row[k] > mx ? row[k] : mx;
     T sum = T(0);
     if (live)
-      for (int k = 0; k < K; ++k) sum += exp(row[k] - mx);
+      for (int k = 0; k < K; ++k) {
+        const T e = exp(row[k] - mx);  // one exp per entry; normalised by a multiply below
+        row[k] = e;
+        sum += e;
+      }
     const T lse = live ? mx + log(sum) : T(0);
+    const T inv = live ? T(1) / sum : T(0);
     for (int k = 0; k < K; ++k) {
       T v = T(0);
       if (live) {
-        v = exp(row[k] - lse);
+        v = row[k] * inv;
         row[k] = v;
       }
 #pragma unroll
@@ -630,6 +723,10 @@ static int wmom_dispatch(const T* X, const T* p, int64_t S, int64_t Bo, int64_t 
   hipStream_t st = (hipStream_t)stream;
   // dense contraction over many samples: matrix cores (see k_wmom_mfma)
   if (Bi == 1 && Bo <= 64 && S >= 4096) {
+    if (D == 1) return wmom_small<T, 1>(X, p, S, Bo, Nk, SEx, SExx, st);
+    if (D == 2) return wmom_small<T, 2>(X, p, S, Bo, Nk, SEx, SExx, st);
+    if (D == 3) return wmom_small<T, 3>(X, p, S, Bo, Nk, SEx, SExx, st);
+    if (D == 4) return wmom_small<T, 4>(X, p, S, Bo, Nk, SEx, SExx, st);
     if constexpr (sizeof(T) == 4) {
       if (D <= 16) return wmom_mfma<float, 16>(X, p, S, Bo, D, Nk, SEx, SExx, st);
       if (D <= 64) return wmom_mfma<float, 32>(X, p, S, Bo, D, Nk, SEx, SExx, st);

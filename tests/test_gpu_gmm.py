@@ -177,7 +177,7 @@ def test_gmm_sample_sharded_matches_single(golden):
         assert_close(m.logZ, ref.logZ, 1e-10)
 
 
-@pytest.mark.parametrize("K,D,N", [(1, 64, 50001), (3, 40, 20000), (4, 16, 8191 * 2), (2, 33, 4097), (9, 16, 8192)])
+@pytest.mark.parametrize("K,D,N", [(1, 64, 50001), (3, 40, 20000), (4, 16, 8191 * 2), (2, 33, 4097), (9, 16, 8192), (4, 2, 70001), (3, 4, 5000)])
 def test_weighted_moments_mfma_fp32(K, D, N):
     """fp32 K4 on the matrix cores (v_mfma_f32_32x32x2_f32 over the sample axis) against an fp64 einsum"""
     from pyvbmp_amd import ops
@@ -196,7 +196,8 @@ def test_weighted_moments_mfma_fp32(K, D, N):
     assert abs(float(Nk[0]) - N) < 1e-3 * N
 
 
-@pytest.mark.parametrize("K,D,N", [(1, 32, 30001), (4, 16, 50000), (3, 2, 9000), (2, 21, 4099), (11, 16, 8191), (6, 24, 5000)])
+@pytest.mark.parametrize("K,D,N", [(1, 32, 30001), (4, 16, 50000), (3, 2, 9000), (2, 21, 4099), (11, 16, 8191), (6, 24, 5000), (5, 1, 7000),
+                                   (7, 3, 6001), (4, 4, 100003)])
 def test_weighted_moments_mfma_fp64(K, D, N):
     """fp64 K4 on v_mfma_f64_16x16x4_f64 against an einsum, at the fp64 parity tolerance"""
     from pyvbmp_amd import ops
