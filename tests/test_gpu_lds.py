@@ -177,3 +177,32 @@ def test_lds_graphed_update_matches_eager(noise):
     assert_close(b.A.mu, a.A.mu, 1e-8, what="A.mu")
     assert_close(b.obs_model.mu, a.obs_model.mu, 1e-8, what="obs.mu")
     assert_close(b.ELBO().sum(), a.ELBO().sum(), 1e-8, what="ELBO")
+
+
+@pytest.mark.parametrize("form", ["rows", "lanes"])
+@pytest.mark.parametrize("h", [1, 2, 3, 5, 7, 8])
+def test_lds_smoother_every_hidden_dim_both_forms(h, form, smoother_form):
+    """K9 for every hidden dimension it is instantiated for, in both device forms, with a series count that leaves the
+    last wave of the row-per-lane form (4 series per wave) and of the lane-per-series form partly empty: px.* and the
+    evidence against the CPU oracle."""
+    from oracle import lds as olds
+    from oracle import mnw as omnw
+    from oracle import niw as oniw
+    from pyvbmp_amd.models import LinearDynamicalSystems
+    smoother_form(form)
+    T, S = 40, 13
+    g = torch.Generator().manual_seed(100 + h)
+    y = lorenz(T, S, g)
+    m = LinearDynamicalSystems((6,), h, latent_noise='shared', device=DEV, dtype=torch.float64)
+    x0 = oniw.niw_new((h,), (), mu_init=m.x0.mu.cpu())
+    A = omnw.mnw_new((h, h + 1), (), mu_init=m.A.mu.cpu())
+    obs = omnw.mnw_new((6, h + 1), (), mu_init=m.obs_model.mu.cpu())
+    yy, uu, rr = m.reshape_inputs(y.to(DEV))
+    m.update_latents(yy, uu, rr)
+    yo, uo, ro = olds.reshape_inputs(y, None, None, (6,), 1, 1)
+    sm = olds.smoother(olds.latent_parms(A, h), x0, h, yo, uo, ro, obs, 0)
+    for f in ("mu", "Sigma", "invSigma", "invSigmamu"):
+        assert_close(getattr(m.px, f), sm[f], 1e-9, what=f)
+    st = olds.latent_stats(sm, yo, uo, ro, (6,), 1, 1, (), 0)
+    assert_close(m.logZ, st["logZ"], 1e-9, what="logZ")
+    assert_close(m.SE_x_xpu, st["SE_x_xpu"], 1e-9, what="SE_x_xpu")
