@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VBMP_ABI_VERSION 1
+#define VBMP_ABI_VERSION 2
 int vbmp_abi_version(void);
 
 /* K1 -- Ainv = A^-1 and logdet = log det A of B symmetric positive definite matrices.
@@ -124,6 +124,11 @@ int vbmp_weighted_moments_f32(const float* X, const float* p, int64_t S, int64_t
  * x0_res = -1/2 EXTinvUX + 1/2 ElogdetinvSigma - H/2 log 2pi of the initial-state prior (:349).
  * Outputs are dense: invSigma/Sigma/Sigma_t_tp1 (T,S,H,H), invSigmamu/mu (T,S,H), logZ (T,S),
  * Sigma_x0_x0 (S,H,H), mu_x0 (S,H).  All blocks must be 16-byte aligned.
+ * sum_xx / sum_xpx (nullable, dense (S,H,H)) receive the time-integrated latent statistics of update_latents
+ * (models/LinearDynamicalSystems.py:173-178) that the backward sweep already holds in registers:
+ *     sum_xx[s]  = sum_{t<T}   Sigma[t,s] + mu[t,s] mu[t,s]'
+ *     sum_xpx[s] = sum_{t<T-1} Sigma_t_tp1[t,s] + mu[t,s] mu[t+1,s]'
+ * so that the two largest outputs are not read back from HBM for their time sums.
  * Two device forms, chosen by S: one series per 16-lane DPP row (S <= 32768: 4 series per wave, so that few
  * thousand series already cover every SIMD) and one series per lane (more series). */
 #define VBMP_LDS_MAX_H 8
@@ -140,6 +145,7 @@ int vbmp_weighted_moments_f32(const float* X, const float* p, int64_t S, int64_t
     const REAL* cu2;      int64_t c2_t, c2_s, c2_b;                                                           \
     const REAL* cu3;      int64_t c3_t, c3_s, c3_b;                                                           \
     REAL *invSigma, *invSigmamu, *Sigma, *mu, *Sigma_t_tp1, *logZ, *Sigma_x0_x0, *mu_x0;                      \
+    REAL *sum_xx, *sum_xpx; /* nullable (S,H,H): time-integrated second moments, see above */                  \
   } vbmp_lds_args_##SUF;
 VBMP_DECL_LDS_ARGS(f64, double)
 VBMP_DECL_LDS_ARGS(f32, float)

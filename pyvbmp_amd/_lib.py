@@ -16,7 +16,7 @@ _c_i64 = ctypes.c_int64
 _c_int = ctypes.c_int
 _c_ptr = ctypes.c_void_p
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 
@@ -59,7 +59,8 @@ def lds_args_struct(cT):
     fields += [(n, P) for n in ("invQ", "ATQA_xx", "QA_xp_x", "A_Elogdet", "x0_P", "x0_eta", "x0_res")]
     for n, pre in (("like_P", "lP"), ("like_eta", "le"), ("like_res", "lr"), ("cu1", "c1"), ("cu2", "c2"), ("cu3", "c3")):
         fields += [(n, P), (pre + "_t", _c_i64), (pre + "_s", _c_i64), (pre + "_b", _c_i64)]
-    fields += [(n, P) for n in ("invSigma", "invSigmamu", "Sigma", "mu", "Sigma_t_tp1", "logZ", "Sigma_x0_x0", "mu_x0")]
+    fields += [(n, P) for n in ("invSigma", "invSigmamu", "Sigma", "mu", "Sigma_t_tp1", "logZ", "Sigma_x0_x0", "mu_x0",
+                                "sum_xx", "sum_xpx")]
     return type("vbmp_lds_args", (ctypes.Structure,), {"_fields_": fields})
 
 

@@ -182,11 +182,13 @@ class LinearDynamicalSystems():
         mv, yv, uv, rv = mu.squeeze(-1), y.squeeze(-1), u.squeeze(-1), r.squeeze(-1)
         ts = ops.tsum_outer
         SE_x0_x0 = Sigma_x0_x0 + SE_x0 @ _T(SE_x0)
-        SE_x_x = ts(mv, mv, M=Sig)
+        sum_xx, sum_xpx = getattr(self, "_time_sums", (None, None))
+        SE_x_x = sum_xx if sum_xx is not None else ts(mv, mv, M=Sig)
         SE_xp_xp = SE_x_x - (mu[-1] @ _T(mu[-1]) + Sig[-1]) + SE_x0_x0
         SE_x_u = ts(mv, uv)
         SE_xp_u = ts(mv, uv, b_from=1, steps=Tn - 1) + SE_x0 @ _T(u[0])
-        SE_xp_x = ts(mv, mv, M=Sigma_t_tp1, b_from=1, steps=Tn - 1) + SE_x0 @ _T(mu[0]) + Sigma_t_tp1[-1]
+        SE_xp_x = (sum_xpx if sum_xpx is not None else ts(mv, mv, M=Sigma_t_tp1, b_from=1, steps=Tn - 1)) \
+            + SE_x0 @ _T(mu[0]) + Sigma_t_tp1[-1]
         SE_x_r = ts(mv, rv)
         SE_x_y = ts(mv, yv)
         SE_u_u = ts(uv, uv)
@@ -312,6 +314,8 @@ class LinearDynamicalSystems():
         self.px.Sigma = out["Sigma"]
         self.px.mu = out["mu"].unsqueeze(-1)
         self.px.logdetinvSigma = None
+        # K9 accumulates the two matrix-valued time sums of update_latents in its backward sweep (None when composed)
+        self._time_sums = (out.get("sum_xx"), out.get("sum_xpx"))
         return out["Sigma_t_tp1"], out["Sigma_x0_x0"], out["mu_x0"].unsqueeze(-1), out["logZ"], None
 
     def _smoother_composed(self, T, lead, P_like, eta_like, res_like, cu1, cu2, cu3, x0_res):

@@ -286,7 +286,10 @@ def lds_smoother(T, sample_shape, bo_shape, H, invQ, ATQA_xx, QA_xp_x, A_Elogdet
            "Sigma_t_tp1": torch.empty(lead + (H, H), dtype=dt, device=dev),
            "logZ": torch.empty(lead, dtype=dt, device=dev),
            "Sigma_x0_x0": torch.empty(lead[1:] + (H, H), dtype=dt, device=dev),
-           "mu_x0": torch.empty(lead[1:] + (H,), dtype=dt, device=dev)}
+           "mu_x0": torch.empty(lead[1:] + (H,), dtype=dt, device=dev),
+           # time-integrated second moments, accumulated in the backward sweep's registers
+           "sum_xx": torch.empty(lead[1:] + (H, H), dtype=dt, device=dev),
+           "sum_xpx": torch.empty(lead[1:] + (H, H), dtype=dt, device=dev)}
     a = L.LDS_ARGS[suf]()
     a.T, a.S, a.NB, a.H = T, S, NB, H
     for name, t in zip(("invQ", "ATQA_xx", "QA_xp_x", "A_Elogdet", "x0_P", "x0_eta", "x0_res"), keep):
