@@ -1,95 +1,91 @@
-"""Gamma posterior (conjugate prior of a Poisson rate / of a diagonal precision entry).  O(B.D) elementwise
-arithmetic: plain torch ops on the device.  Surface of the reference's dists/Gamma.py:6-105."""
+"""Gamma posterior: conjugate prior of a Poisson rate and of one diagonal precision entry (DiagonalWishart, the ARD
+prior of MVN_ard).  Surface of the reference's dists/Gamma.py:6-105.
+
+Only O(batch x event) elementwise arithmetic happens here, so it is plain torch on the device: the conjugate update
+is a blend of natural parameters, and every expectation is a closed form of the shape `a` and the rate `b`, kept in
+one table (name -> formula) from which the reference's getter methods are generated.
+"""
 import torch
 
 from .._common import as_param, resolve
 
+# closed forms of Gamma(shape a, rate b)
+_FORMULAS = {
+    "mean": lambda a, b: a / b,
+    "var": lambda a, b: a / b ** 2,
+    "meaninv": lambda a, b: b / (a - 1),
+    "ElogX": lambda a, b: torch.digamma(a) - torch.log(b),
+    "loggeomean": lambda a, b: torch.log(a) - torch.log(b),
+    "entropy": lambda a, b: torch.log(a) - torch.log(b) + torch.lgamma(a) + (1 - a) * torch.digamma(a),
+    "logZ": lambda a, b: torch.lgamma(a) - a * torch.log(b),
+}
+
 
 class Gamma():
     def __init__(self, event_shape=(), batch_shape=(), prior_parms=None, device=None, dtype=None):
-        if prior_parms is None:
-            prior_parms = {'alpha': 1.0, 'beta': 1.0}
         self.device, self.dtype = resolve(device, dtype)
+        self.nat_parms_0 = prior_parms = {'alpha': 1.0, 'beta': 1.0} if prior_parms is None else prior_parms
         self.event_shape, self.batch_shape = tuple(event_shape), tuple(batch_shape)
         self.event_dim, self.batch_dim = len(self.event_shape), len(self.batch_shape)
-        self.nat_parms_0 = prior_parms
-        full = self.batch_shape + self.event_shape
-        self.alpha_0 = as_param(prior_parms['alpha'], self.device, self.dtype).expand(full)
-        self.beta_0 = as_param(prior_parms['beta'], self.device, self.dtype).expand(full)
-        self.alpha = self.alpha_0 + torch.rand(full, device=self.device, dtype=self.dtype)
-        self.beta = self.beta_0 + torch.rand(full, device=self.device, dtype=self.dtype)
-        self.SEx = 0.0
-        self.SElogx = 0.0
+        shape = self.batch_shape + self.event_shape
+        kw = dict(device=self.device, dtype=self.dtype)
+        for key in ("alpha", "beta"):
+            prior = as_param(prior_parms[key], self.device, self.dtype).expand(shape)
+            setattr(self, key + "_0", prior)
+            setattr(self, key, prior + torch.rand(shape, **kw))  # the reference starts off the prior (:20-21)
+        self.SEx = self.SElogx = 0.0  # forgetting-factor accumulators
 
     def _ev(self):
         return tuple(range(-self.event_dim, 0))
 
     def to_event(self, n):
-        if n == 0:
-            return self
-        self.event_dim = self.event_dim + n
-        self.batch_dim = self.batch_dim - n
-        self.event_shape = self.batch_shape[-n:] + self.event_shape
-        self.batch_shape = self.batch_shape[:-n]
+        if n != 0:
+            self.event_dim, self.batch_dim = self.event_dim + n, self.batch_dim - n
+            self.event_shape = self.batch_shape[-n:] + self.event_shape
+            self.batch_shape = self.batch_shape[:-n]
         return self
 
     def ss_update(self, SElogx, SEx, lr=1.0, beta=None):
-        assert (SElogx.ndim == self.batch_dim + self.event_dim)
-        assert (SEx.ndim == self.batch_dim + self.event_dim)
+        """natural-parameter blend: shape <- prior shape + SElogx, rate <- prior rate + SEx (ref :34-46)"""
+        nd = self.batch_dim + self.event_dim
+        assert SElogx.ndim == nd and SEx.ndim == nd
         if beta is not None:
-            self.SEx = beta * self.SEx + SEx
-            self.SElogx = beta * self.SElogx + SElogx
+            self.SEx, self.SElogx = beta * self.SEx + SEx, beta * self.SElogx + SElogx
             SEx, SElogx = self.SEx, self.SElogx
-        self.alpha = (self.alpha_0 + SElogx) * lr + self.alpha * (1 - lr)
-        self.beta = (self.beta_0 + SEx) * lr + self.beta * (1 - lr)
+        self.alpha = lr * (self.alpha_0 + SElogx) + (1 - lr) * self.alpha
+        self.beta = lr * (self.beta_0 + SEx) + (1 - lr) * self.beta
 
     def _count_and_sum(self, X, p):
-        sd = tuple(range(X.ndim - self.event_dim - self.batch_dim))
-        if p is None:
-            n = 1
-            for i in sd:
-                n *= X.shape[i]
-            N = torch.tensor(float(n), device=X.device, dtype=X.dtype).expand(self.batch_shape + self.event_shape)
-            return X.sum(sd), N
-        pe = p.reshape(tuple(p.shape) + (1,) * self.event_dim)
-        return (X * pe).sum(sd), pe.sum(sd)
-
-    def update(self, pX, p=None, lr=1.0, beta=None):
-        SEx, N = self._count_and_sum(pX.mean(), p)
-        self.ss_update(SEx, N, lr=lr, beta=beta)
+        """(sum_s p_s x_s, sum_s p_s) over the sample axes; p None = unit weights"""
+        sample_axes = tuple(range(X.ndim - self.event_dim - self.batch_dim))
+        if p is not None:
+            w = p.reshape(tuple(p.shape) + (1,) * self.event_dim)
+            return (X * w).sum(sample_axes), w.sum(sample_axes)
+        count = 1
+        for ax in sample_axes:
+            count *= X.shape[ax]
+        N = torch.tensor(float(count), device=X.device, dtype=X.dtype).expand(self.batch_shape + self.event_shape)
+        return X.sum(sample_axes), N
 
     def raw_update(self, X, p=None, lr=1.0, beta=None):
-        SEx, N = self._count_and_sum(X, p)
-        self.ss_update(SEx, N, lr=lr, beta=beta)
+        self.ss_update(*self._count_and_sum(X, p), lr=lr, beta=beta)
+
+    def update(self, pX, p=None, lr=1.0, beta=None):
+        self.ss_update(*self._count_and_sum(pX.mean(), p), lr=lr, beta=beta)
 
     def Elog_like(self, X):
-        return (X * self.loggeomean() - (X + 1).lgamma() - self.mean()).sum(self._ev())
-
-    def mean(self):
-        return self.alpha / self.beta
-
-    def var(self):
-        return self.alpha / self.beta ** 2
-
-    def meaninv(self):
-        return self.beta / (self.alpha - 1)
-
-    def ElogX(self):
-        return self.alpha.digamma() - self.beta.log()
-
-    def loggeomean(self):
-        return self.alpha.log() - self.beta.log()
-
-    def entropy(self):
-        return self.alpha.log() - self.beta.log() + self.alpha.lgamma() + (1 - self.alpha) * self.alpha.digamma()
-
-    def logZ(self):
-        return -self.alpha * self.beta.log() + self.alpha.lgamma()
+        """expected Poisson log-likelihood of counts X under the rate posterior (ref :76-77)"""
+        return (X * self.loggeomean() - torch.lgamma(X + 1) - self.mean()).sum(self._ev())
 
     def logZprior(self):
-        return -self.alpha_0 * self.beta_0.log() + self.alpha_0.lgamma()
+        return _FORMULAS["logZ"](self.alpha_0, self.beta_0)
 
     def KLqprior(self):
-        KL = (self.alpha - self.alpha_0) * self.alpha.digamma() - self.alpha.lgamma() + self.alpha_0.lgamma() \
-            + self.alpha_0 * (self.beta.log() - self.beta_0.log()) + self.alpha * (self.beta_0 / self.beta - 1)
-        return KL.sum(self._ev())
+        a, b, a0, b0 = self.alpha, self.beta, self.alpha_0, self.beta_0
+        kl = (a - a0) * torch.digamma(a) - torch.lgamma(a) + torch.lgamma(a0) + a0 * (torch.log(b) - torch.log(b0)) \
+            + a * (b0 / b - 1)
+        return kl.sum(self._ev())
+
+
+for _name, _formula in _FORMULAS.items():
+    setattr(Gamma, _name, (lambda f: lambda self: f(self.alpha, self.beta))(_formula))

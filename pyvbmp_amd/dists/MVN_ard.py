@@ -38,63 +38,56 @@ class MVN_ard():
         self.batch_shape = self.batch_shape[:-n]
         return self
 
-    def ss_update(self, SExx, SEx, iters=2, lr=1.0, beta=None):
-        """ref :48-72 (including its first mean, which is formed with the PREVIOUS natural mean, :58)"""
-        if beta is not None:
-            self.SExx = self.SExx * beta + SExx
-            self.SEx = self.SEx * beta + SEx
-            SExx, SEx = self.SExx, self.SEx
+    def _precision(self, SExx, jitter=0.0):
+        """data precision + expected ARD precisions on the diagonal (+ the reference's start-up jitter)"""
         eye = torch.eye(self.dim, device=self.device, dtype=self.dtype)
-        invSigmamu = SEx
-        invSigma = SExx + self.alpha.mean() * eye + 1e-6 * eye
-        Sigma = ops.spd_inverse(invSigma)
-        mu = Sigma @ self.invSigmamu
+        return SExx + (self.alpha.mean() + jitter) * eye
+
+    def ss_update(self, SExx, SEx, iters=2, lr=1.0, beta=None):
+        """Coordinate ascent between the Gaussian factor and the Gamma factor of the ARD prior (ref :48-72).
+        SExx: batch + (n, p, p) data precision, SEx: batch + (n, p, 1) natural mean.  Each sweep: the Gamma factor
+        sees E[x_i^2] = Sigma_ii + mu_i^2, the Gaussian factor the new expected precisions.  The reference forms its
+        very first mean with the PREVIOUS natural mean (:58); kept, since the first Gamma sweep depends on it."""
+        if beta is not None:
+            self.SExx, self.SEx = self.SExx * beta + SExx, self.SEx * beta + SEx
+            SExx, SEx = self.SExx, self.SEx
         half = torch.full((), 0.5, device=self.device, dtype=self.dtype).expand(self.alpha.batch_shape + self.alpha.event_shape)
-        for i in range(iters):
-            EXXT = Sigma.diagonal(dim1=-1, dim2=-2).unsqueeze(-1) + mu ** 2
-            self.alpha.ss_update(half, 0.5 * EXXT, lr=lr, beta=beta)
-            invSigma = SExx + self.alpha.mean() * eye
-            Sigma = ops.spd_inverse(invSigma)
-            mu = Sigma @ invSigmamu
-        self.invSigma = (1 - lr) * self.invSigma + lr * invSigma
-        self.invSigmamu = (1 - lr) * self.invSigmamu + lr * invSigmamu
+        precision = self._precision(SExx, jitter=1e-6)
+        cov = ops.spd_inverse(precision)
+        mean = cov @ self.invSigmamu
+        for sweep in range(iters):
+            second_moment = cov.diagonal(dim1=-1, dim2=-2).unsqueeze(-1) + mean ** 2
+            self.alpha.ss_update(half, 0.5 * second_moment, lr=lr, beta=beta)
+            precision = self._precision(SExx)
+            cov = ops.spd_inverse(precision)
+            mean = cov @ SEx
+        self.invSigma = lr * precision + (1 - lr) * self.invSigma
+        self.invSigmamu = lr * SEx + (1 - lr) * self.invSigmamu
         self.Sigma, self.logdetinvSigma = ops.spd_inv_logdet(self.invSigma)
         self.mu = self.Sigma @ self.invSigmamu
 
     def KLqprior(self):
         ev = list(range(-self.event_dim, 0))
         KL = 0.5 * (self.mu.pow(2) * self.alpha.mean()).sum(ev)
-        KL = KL - 0.5 * self.alpha.loggeomean().sum(ev) + 0.5 * self.ElogdetinvSigma().sum(list(range(2 - self.event_dim, 0)))
+        KL = KL - 0.5 * self.alpha.loggeomean().sum(ev) + 0.5 * self.logdetinvSigma.sum(list(range(2 - self.event_dim, 0)))
         KL = KL + (self.Sigma.diagonal(dim1=-1, dim2=-2) * self.alpha.mean().squeeze(-1)).sum(list(range(1 - self.event_dim, 0)))
         return KL + self.alpha.KLqprior()
 
-    def mean(self):
-        return self.mu
-
-    def ESigma(self):
-        return self.Sigma
-
-    def EinvSigma(self):
-        return self.invSigma
-
-    def EinvSigmamu(self):
-        return self.invSigmamu
-
-    def ElogdetinvSigma(self):
-        return self.logdetinvSigma
-
-    def EX(self):
-        return self.mean()
-
     def EXXT(self):
-        return self.ESigma() + self.mean() @ self.mean().transpose(-2, -1)
+        return self.Sigma + self.mu @ self.mu.transpose(-2, -1)
 
     def EXTX(self):
-        return self.ESigma().sum(-1).sum(-1) + self.mean().pow(2).sum(-2).squeeze(-1)
+        return self.Sigma.sum(-1).sum(-1) + self.mu.pow(2).sum(-2).squeeze(-1)
 
     def EXTinvUX(self):
-        return (self.mean().transpose(-2, -1) @ self.EinvSigma() @ self.mean()).squeeze(-1).squeeze(-1)
+        return (self.mu.transpose(-2, -1) @ self.invSigma @ self.mu).squeeze(-1).squeeze(-1)
 
     def Res(self):
-        return - 0.5 * (self.mean() * self.EinvSigmamu()).sum(-1).sum(-1) + 0.5 * self.ElogdetinvSigma() \
+        return - 0.5 * (self.mu * self.invSigmamu).sum(-1).sum(-1) + 0.5 * self.logdetinvSigma \
             - 0.5 * self.dim * torch.log(2 * torch.tensor(torch.pi, device=self.device, dtype=self.dtype))
+
+
+# the cached moments / natural parameters under the reference's getter names (dists/MVN_ard.py:81-97)
+for _getter, _attr in {"mean": "mu", "EX": "mu", "ESigma": "Sigma", "EinvSigma": "invSigma", "EinvSigmamu": "invSigmamu",
+                       "ElogdetinvSigma": "logdetinvSigma"}.items():
+    setattr(MVN_ard, _getter, (lambda a: lambda self: getattr(self, a))(_attr))

@@ -74,35 +74,39 @@ class Wishart():
     def _nu2(self):
         return trailing(self.nu, 2)
 
-    def mean(self):
-        return self.U * self._nu2()
-
-    def meaninv(self):
-        return self.invU / (self._nu2() - self.dim - 1)
-
-    def ESigma(self):
-        return self.invU / (self._nu2() - self.dim - 1)
-
-    def EinvSigma(self):
-        return self.U * self._nu2()
-
-    def invEinvSigma(self):
-        return self.invU / self._nu2()
+    def _half_nu_terms(self, nu, fn):
+        """sum_i fn(nu/2 - i/2), i < dim: the multivariate (di)gamma sums of the Wishart normaliser"""
+        return fn(0.5 * nu.unsqueeze(-1) - self._arange).sum(-1)
 
     def ElogdetinvSigma(self):
-        return self.dim * _LOG2 - self.logdet_invU + self.log_mvdigamma(self.nu / 2.0)
+        return self._half_nu_terms(self.nu, torch.digamma) + self.dim * _LOG2 - self.logdet_invU
 
     def logdetEinvSigma(self):
-        return -self.logdet_invU + self.nu.log()
+        return torch.log(self.nu) - self.logdet_invU
 
     def KLqprior(self):
-        out = self.nu_0 / 2.0 * (self.logdet_invU - self.logdet_invU_0) \
-            + self.nu / 2.0 * (self.invU_0 * self.U).sum((-1, -2)) - self.nu * self.dim / 2.0
-        out = out + self.log_mvgamma(self.nu_0 / 2.0) - self.log_mvgamma(self.nu / 2.0) \
-            + (self.nu - self.nu_0) / 2.0 * self.log_mvdigamma(self.nu / 2.0)
-        for i in range(self.event_dim - 2):
-            out = out.sum(-1)
-        return out
+        half, half0 = 0.5 * self.nu, 0.5 * self.nu_0
+        trace_term = (self.invU_0 * self.U).sum((-1, -2))  # tr(invU_0 U)
+        kl = half0 * (self.logdet_invU - self.logdet_invU_0) + half * (trace_term - self.dim)
+        kl = kl + self._half_nu_terms(self.nu_0, torch.lgamma) - self._half_nu_terms(self.nu, torch.lgamma) \
+            + (half - half0) * self._half_nu_terms(self.nu, torch.digamma)
+        for _ in range(self.event_dim - 2):
+            kl = kl.sum(-1)
+        return kl
 
     def logZ(self):
-        return self.log_mvgamma(self.nu / 2.0) + 0.5 * self.nu * self.dim * _LOG2 - 0.5 * self.nu * self.logdet_invU
+        half = 0.5 * self.nu
+        return self._half_nu_terms(self.nu, torch.lgamma) + half * (self.dim * _LOG2 - self.logdet_invU)
+
+
+# matrix-valued expectations under the reference's names (dists/Wishart.py:67-80): a cached matrix times or over a
+# function of the degrees of freedom
+for _name, _matrix, _scale in (("mean", "U", lambda nu, d: nu), ("EinvSigma", "U", lambda nu, d: nu),
+                               ("meaninv", "invU", lambda nu, d: 1.0 / (nu - d - 1)),
+                               ("ESigma", "invU", lambda nu, d: 1.0 / (nu - d - 1)),
+                               ("invEinvSigma", "invU", lambda nu, d: 1.0 / nu)):
+    def _make(matrix, scale):
+        def method(self):
+            return getattr(self, matrix) * scale(self._nu2(), self.dim)
+        return method
+    setattr(Wishart, _name, _make(_matrix, _scale))

@@ -13,12 +13,25 @@ def _weight(p, k):
     return p.reshape(tuple(p.shape) + (1,) * k)
 
 
+def _emission(dim, n, p, batch_shape, pad_X, X_mask, mask, device, dtype):
+    """one MatrixNormalWishart regression y = A x per hidden state: the states are its last batch axis"""
+    return MatrixNormalWishart(event_shape=(n, p), batch_shape=tuple(batch_shape) + (dim,), pad_X=pad_X, X_mask=X_mask,
+                               mask=mask, device=device, dtype=dtype)
+
+
+def _role_average(p, P, eta, Res):
+    """natural-parameter message to x averaged over the state posterior p (None = leave per-state)"""
+    if p is None:
+        return P, eta, Res
+    w = _weight(p, 2)
+    return (P * w).sum(-3), (eta * w).sum(-3), (Res * p).sum(-1)
+
+
 class ARHMM(HMM):
     def __init__(self, dim, n, p, batch_shape=(), pad_X=True, X_mask=None, mask=None, transition_mask=None,
                  device=None, dtype=None):
-        dist = MatrixNormalWishart(event_shape=(n, p), batch_shape=tuple(batch_shape) + (dim,), pad_X=pad_X, X_mask=X_mask,
-                                   mask=mask, device=device, dtype=dtype)
-        super().__init__(dist, transition_mask=transition_mask)
+        super().__init__(_emission(dim, n, p, batch_shape, pad_X, X_mask, mask, device, dtype),
+                         transition_mask=transition_mask)
 
     def obs_logits(self, XY, t=None):
         if t is not None:
@@ -32,9 +45,8 @@ class ARHMM(HMM):
 class ARHMM_prXY(HMM):
     def __init__(self, dim, n, p, batch_shape=(), X_mask=None, mask=None, pad_X=True, transition_mask=None,
                  device=None, dtype=None):
-        dist = MatrixNormalWishart(event_shape=(n, p), batch_shape=tuple(batch_shape) + (dim,), pad_X=pad_X, X_mask=X_mask,
-                                   mask=mask, device=device, dtype=dtype)
-        super().__init__(dist, transition_mask=transition_mask)
+        super().__init__(_emission(dim, n, p, batch_shape, pad_X, X_mask, mask, device, dtype),
+                         transition_mask=transition_mask)
 
     def obs_logits(self, XY):
         return self.obs_dist.Elog_like_given_pX_pY(XY[0], XY[1])
@@ -44,12 +56,7 @@ class ARHMM_prXY(HMM):
 
     def Elog_like_X_given_pY(self, pY):
         px, Res = self.obs_dist.Elog_like_X_given_pY(pY)
-        P, eta = px.invSigma, px.invSigmamu
-        if self.p is not None:
-            P = (P * _weight(self.p, 2)).sum(-3)
-            eta = (eta * _weight(self.p, 2)).sum(-3)
-            Res = (Res * self.p).sum(-1)
-        return P, eta, Res
+        return _role_average(self.p, px.invSigma, px.invSigmamu, Res)
 
 
 class ARHMM_prXRY(HMM):
@@ -59,9 +66,8 @@ class ARHMM_prXRY(HMM):
                  device=None, dtype=None):
         self.p1 = p1
         self.p2 = p2
-        dist = MatrixNormalWishart(event_shape=(n, p1 + p2), batch_shape=tuple(batch_shape) + (dim,), pad_X=pad_X,
-                                   X_mask=X_mask, mask=mask, device=device, dtype=dtype)
-        super().__init__(dist, transition_mask=transition_mask)
+        super().__init__(_emission(dim, n, p1 + p2, batch_shape, pad_X, X_mask, mask, device, dtype),
+                         transition_mask=transition_mask)
 
     def _joint_input(self, XRY):
         """[x; r] as one Gaussian: covariance block-diag(Sigma_x, 0), mean [mu_x; r] (ref :59-66)"""
@@ -90,8 +96,4 @@ class ARHMM_prXRY(HMM):
         eta = eta_xr[..., :p1, :] - P_xr[..., :p1, p1:] @ R
         Res = Res - 0.5 * (P_xr[..., p1:, p1:] * (R * R.transpose(-2, -1))).sum((-1, -2))
         Res = Res + (eta_xr[..., p1:, :] * R).sum((-1, -2))
-        if self.p is not None:
-            P = (P * _weight(self.p, 2)).sum(-3)
-            eta = (eta * _weight(self.p, 2)).sum(-3)
-            Res = (Res * self.p).sum(-1)
-        return P, eta, Res
+        return _role_average(self.p, P, eta, Res)

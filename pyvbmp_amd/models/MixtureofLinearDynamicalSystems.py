@@ -31,12 +31,10 @@ class MixtureofLinearDynamicalSystems():
         for i in range(iters):
             ELBO_last = ELBO
             self.lds.update_latents(y, u, r)
+            # responsibilities of every system for every series: softmax of evidence + expected log mixing weight
             log_p = self.lds.logZ + self.pi.loggeomean()
-            shift = log_p.max(-1, True)[0]
-            log_p = log_p - shift
-            self.logZ = (log_p.logsumexp(-1, True) + shift).squeeze(-1)  # sample shape
-            self.p = torch.exp(log_p)
-            self.p = self.p / self.p.sum(-1, True)
+            self.logZ = torch.logsumexp(log_p, -1)  # sample shape
+            self.p = torch.exp(log_p - self.logZ.unsqueeze(-1))
             self.NA = self.p.sum(0)
             red = self.lds.reducer
             if red is not None:

@@ -140,48 +140,6 @@ class MixtureofLinearTransforms():
             out = out.sum(-1)
         return out
 
-    def EinvUX(self):
-        return self.event_average(self.W.EinvUX())
-
-    def EXTinvU(self):
-        return self.event_average(self.W.EXTinvU())
-
-    def EXTAX(self, A):
-        return self.event_average(self.W.EXTAX(A))
-
-    def EXAXT(self, A):
-        return self.event_average(self.W.EXAXT(A))
-
-    def EXTinvUX(self):
-        return self.event_average(self.W.EXTinvUX())
-
-    def EXinvVXT(self):
-        return self.event_average(self.W.EXinvVXT())
-
-    def EXmMUTinvUXmMU(self):
-        return self.event_average(self.W.EXmMUTinvUXmMU())
-
-    def EXmMUinvVXmMUT(self):
-        return self.event_average(self.W.EXmMUinvVXmMUT())
-
-    def EXTX(self):
-        return self.event_average(self.W.EXTX())
-
-    def EXXT(self):
-        return self.event_average(self.W.EXXT())
-
-    def EinvSigma(self):
-        return self.event_average(self.W.EinvSigma())
-
-    def ESigma(self):
-        return self.event_average(self.W.ESigma())
-
-    def ElogdetinvU(self):
-        return self.average(self.W.invU.ElogdetinvSigma())
-
-    def ElogdetinvSigma(self):
-        return self.average(self.W.ElogdetinvSigma())
-
     def weights(self):
         return self.W.mu[..., :-1] if self.padX else self.W.mu
 
@@ -190,3 +148,25 @@ class MixtureofLinearTransforms():
 
     def means(self):
         return self.W.mu
+
+
+# responsibility-weighted versions of the experts' expectations (ref :151-197): matrix-valued ones through
+# event_average, per-expert scalars through average
+def _weighted(name, arity):
+    if arity == 0:
+        def method(self):
+            return self.event_average(getattr(self.W, name)())
+    else:
+        def method(self, A):
+            return self.event_average(getattr(self.W, name)(A))
+    method.__name__ = name
+    return method
+
+
+for _name in ("EinvUX", "EXTinvU", "EXTinvUX", "EXinvVXT", "EXmMUTinvUXmMU", "EXmMUinvVXmMUT", "EXTX", "EXXT", "EinvSigma",
+              "ESigma"):
+    setattr(MixtureofLinearTransforms, _name, _weighted(_name, 0))
+for _name in ("EXTAX", "EXAXT"):
+    setattr(MixtureofLinearTransforms, _name, _weighted(_name, 1))
+MixtureofLinearTransforms.ElogdetinvU = lambda self: self.average(self.W.invU.ElogdetinvSigma())
+MixtureofLinearTransforms.ElogdetinvSigma = lambda self: self.average(self.W.ElogdetinvSigma())
