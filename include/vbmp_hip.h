@@ -129,9 +129,11 @@ int vbmp_weighted_moments_f32(const float* X, const float* p, int64_t S, int64_t
  *     sum_xx[s]  = sum_{t<T}   Sigma[t,s] + mu[t,s] mu[t,s]'
  *     sum_xpx[s] = sum_{t<T-1} Sigma_t_tp1[t,s] + mu[t,s] mu[t+1,s]'
  * so that the two largest outputs are not read back from HBM for their time sums.
- * Two device forms, chosen by S: one series per 16-lane DPP row (S <= 32768: 4 series per wave, so that few
+ * H <= VBMP_LDS_MAX_H: two register-resident device forms, chosen by S: one series per 16-lane DPP row (S <= 32768: 4 series per wave, so that few
  * thousand series already cover every SIMD) and one series per lane (more series). */
-#define VBMP_LDS_MAX_H 8
+#define VBMP_LDS_MAX_H 8        /* register-resident forms */
+#define VBMP_LDS_MAX_H_BLOCK 64 /* block-per-series form with LDS-resident matrices (8 < H; needs 5 H^2 words of LDS:
+                                   fp64 up to H = 62); larger H return VBMP_ERR_ARG and the caller composes the recursion */
 #define VBMP_DECL_LDS_ARGS(SUF, REAL)                                                                         \
   typedef struct vbmp_lds_args_##SUF {                                                                     \
     int64_t T, S, NB;                                                                                      \

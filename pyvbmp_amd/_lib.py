@@ -65,7 +65,13 @@ def lds_args_struct(cT):
 
 
 LDS_ARGS = {"f64": lds_args_struct(ctypes.c_double), "f32": lds_args_struct(ctypes.c_float)}
-LDS_MAX_H = 8
+LDS_MAX_H = 8          # register-resident smoother forms
+LDS_MAX_H_BLOCK = 64   # block-per-series form (LDS-resident matrices); also bounded by lds_block_fits()
+
+
+def lds_block_fits(h, itemsize):
+    """does the block-per-series smoother's LDS image (five h x h matrices + vectors) fit the CU's 160 KB?"""
+    return (5 * h * (h | 1) + 16 * 72 + 8) * itemsize <= 160 * 1024
 
 
 def _sig_lds(T):

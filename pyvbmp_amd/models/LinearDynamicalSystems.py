@@ -302,7 +302,7 @@ class LinearDynamicalSystems():
         cu3 = (_T(Uc) @ self.ATQA_u_u @ Uc).squeeze(-1).squeeze(-1)
         x0 = self.x0
         x0_res = -0.5 * x0.EXTinvUX() + 0.5 * x0.ElogdetinvSigma() - 0.5 * h * _LOG2PI
-        if h <= ops.L.LDS_MAX_H:
+        if h <= ops.L.LDS_MAX_H or (h <= ops.L.LDS_MAX_H_BLOCK and ops.L.lds_block_fits(h, y.element_size())):
             out = ops.lds_smoother(T_max, sample_shape, bo_shape, h, self.invQ, self.ATQA_x_x, self.QA_xp_x,
                                    self.A.ElogdetinvSigma(), x0.EinvSigma(), x0.EinvSigmamu(), x0_res,
                                    invSigma_like, invSigmamu_like.squeeze(-1), Residual_like, cu1, cu2, cu3)
@@ -319,9 +319,9 @@ class LinearDynamicalSystems():
         return out["Sigma_t_tp1"], out["Sigma_x0_x0"], out["mu_x0"].unsqueeze(-1), out["logZ"], None
 
     def _smoother_composed(self, T, lead, P_like, eta_like, res_like, cu1, cu2, cu3, x0_res):
-        """Same recursion as K9 for hidden_dim > 8 (e.g. the 52-dimensional flocking DMBD): a host loop over time
-        whose every step is batched over the series -- the inverses / logdets are K1 launches, the products
-        rocBLAS GEMMs.  Launch-bound (about 40 launches per time step); the persistent kernel covers h <= 8."""
+        """Same recursion as K9 for hidden dimensions beyond its kernels (h > 64, or fp64 with h > 62 whose matrices
+        do not fit LDS): a host loop over time whose every step is batched over the series -- the inverses / logdets
+        are K1 launches, the products rocBLAS GEMMs.  Launch-bound (about 40 launches per time step)."""
         h = self.hidden_dim
         kw = {"device": eta_like.device, "dtype": eta_like.dtype}
         invQ, ATQA, QA = self.invQ, self.ATQA_x_x, self.QA_xp_x

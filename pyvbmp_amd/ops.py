@@ -263,9 +263,9 @@ def lds_smoother(T, sample_shape, bo_shape, H, invQ, ATQA_xx, QA_xp_x, A_Elogdet
     Returns dict of dense outputs shaped (T,)+sample+bo+(...) (and sample+bo+(...) for the x0 terms)."""
     dev = L.require_device(invQ, like_eta)
     lib = L.load()
-    if H > L.LDS_MAX_H:
-        raise L.VbmpHipError(f"hidden_dim {H} > {L.LDS_MAX_H}: not covered by the HIP smoother yet")
     dt = like_eta.dtype
+    if H > L.LDS_MAX_H and not (H <= L.LDS_MAX_H_BLOCK and L.lds_block_fits(H, dt.itemsize)):
+        raise L.VbmpHipError(f"hidden_dim {H}: beyond the persistent smoother kernels (compose the recursion instead)")
     suf = L.suffix(dt)
     sample_shape, bo_shape = tuple(sample_shape), tuple(bo_shape)
     NB = _prod(bo_shape)

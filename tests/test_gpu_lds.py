@@ -135,6 +135,7 @@ def test_lds_composed_smoother_matches_golden(golden, case, monkeypatch):
     """the hidden_dim > 8 route (host loop of K1 launches + GEMMs) replayed on the golden cases by forcing it"""
     from pyvbmp_amd import _lib
     monkeypatch.setattr(_lib, "LDS_MAX_H", 0)
+    monkeypatch.setattr(_lib, "LDS_MAX_H_BLOCK", 0)
     c = golden("lds")[case]
     m = _make(c)
     dev = lambda k: c[k].to(DEV) if k in c else None  # noqa: E731
@@ -206,3 +207,42 @@ def test_lds_smoother_every_hidden_dim_both_forms(h, form, smoother_form):
     st = olds.latent_stats(sm, yo, uo, ro, (6,), 1, 1, (), 0)
     assert_close(m.logZ, st["logZ"], 1e-9, what="logZ")
     assert_close(m.SE_x_xpu, st["SE_x_xpu"], 1e-9, what="SE_x_xpu")
+
+
+@pytest.mark.parametrize("case", LDS_CASES)
+def test_lds_block_form_matches_golden(golden, case, smoother_flags):
+    """K9's block-per-series form (LDS-resident matrices, meant for 8 < hidden <= 64) forced onto the golden cases"""
+    smoother_flags(0x200)
+    c = golden("lds")[case]
+    m = _make(c)
+    dev = lambda k: c[k].to(DEV) if k in c else None  # noqa: E731
+    y, u, r = m.reshape_inputs(dev("y"), dev("u"), dev("r"))
+    m.update_latents(y, u, r)
+    for f in ("mu", "Sigma", "invSigma", "invSigmamu"):
+        assert_close(getattr(m.px, f), c["it1_px_" + f], 1e-9, what=f)
+    for f in ("SE_x_x", "SE_x0_x0", "SE_x0", "SE_xpu_xpu", "SE_x_xpu", "SE_xr_xr", "logZ"):
+        assert_close(getattr(m, f), c["it1_" + f], 1e-9, what=f)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-8), (torch.float32, 2e-2)])
+@pytest.mark.parametrize("h", [9, 12, 21, 52])
+def test_lds_block_form_vs_composed(h, dtype, tol, monkeypatch):
+    """hidden dimensions beyond the register forms: the block-per-series kernel against the composed recursion
+    (host loop of K1 launches + GEMMs), same model, same data"""
+    from pyvbmp_amd import _lib
+    from pyvbmp_amd.models import LinearDynamicalSystems
+    g = torch.Generator().manual_seed(h)
+    y = lorenz(30, 5, g).to(dtype).to(DEV)
+    torch.manual_seed(h)
+    m = LinearDynamicalSystems((6,), h, latent_noise='shared', device=DEV, dtype=dtype)
+    yy, uu, rr = m.reshape_inputs(y)
+    m.update_latents(yy, uu, rr)
+    got = {f: getattr(m.px, f).clone() for f in ("mu", "Sigma", "invSigma", "invSigmamu")}
+    got.update({f: getattr(m, f).clone() for f in ("SE_x_x", "SE_x_xpu", "logZ")})
+    monkeypatch.setattr(_lib, "LDS_MAX_H_BLOCK", 0)
+    m.px = None
+    m.update_latents(yy, uu, rr)
+    for f in ("mu", "Sigma", "invSigma", "invSigmamu"):
+        assert_close(got[f], getattr(m.px, f), tol, what=f)
+    for f in ("SE_x_x", "SE_x_xpu", "logZ"):
+        assert_close(got[f], getattr(m, f), tol, what=f)
