@@ -363,14 +363,22 @@ static int wmom_mfma(const T* X, const T* p, int64_t S, int64_t Bo, int D, T* Nk
 #define VBMP_WM(NT, BO)                                                                                          \
   hipLaunchKernelGGL((k_wmom_mfma<T, TILE, NT, BO>), g, b, 0, st, X, p ? p + k0 : p, S, D, (int)Bo, Nk + k0,        \
                      SEx + k0 * D, SExx + k0 * D * D)
-  const int nt = D <= TILE ? 1 : 2;
-  // components in groups of four per pass over X (accumulators live in registers)
-  for (int64_t k0 = 0; k0 < Bo; k0 += 4) {
-    const int64_t nb = Bo - k0 < 4 ? Bo - k0 : 4;
+  const int nt = (D + TILE - 1) / TILE;
+  // components in groups per pass over X (accumulators live in registers: BO * NT^2 tiles, so wide statistics take
+  // fewer components per pass: 4 for NT <= 2, 2 for NT = 3, 1 for NT = 4)
+  const int64_t group = nt <= 2 ? 4 : (nt == 3 ? 2 : 1);
+  for (int64_t k0 = 0; k0 < Bo; k0 += group) {
+    const int64_t nb = Bo - k0 < group ? Bo - k0 : group;
     if (nt == 1) {
       if (nb == 1) VBMP_WM(1, 1); else if (nb == 2) VBMP_WM(1, 2); else if (nb == 3) VBMP_WM(1, 3); else VBMP_WM(1, 4);
-    } else {
+    } else if (nt == 2) {
       if (nb == 1) VBMP_WM(2, 1); else if (nb == 2) VBMP_WM(2, 2); else if (nb == 3) VBMP_WM(2, 3); else VBMP_WM(2, 4);
+    } else if constexpr (sizeof(T) == 8 && TILE == 16) {  // fp64 up to D = 64 (fp32 uses the 32-wide tile there)
+      if (nt == 3) {
+        if (nb == 1) VBMP_WM(3, 1); else VBMP_WM(3, 2);
+      } else {
+        VBMP_WM(4, 1);
+      }
     }
   }
 #undef VBMP_WM
@@ -731,7 +739,7 @@ static int wmom_dispatch(const T* X, const T* p, int64_t S, int64_t Bo, int64_t 
       if (D <= 16) return wmom_mfma<float, 16>(X, p, S, Bo, D, Nk, SEx, SExx, st);
       if (D <= 64) return wmom_mfma<float, 32>(X, p, S, Bo, D, Nk, SEx, SExx, st);
     } else {
-      if (D <= 32) return wmom_mfma<double, 16>(X, p, S, Bo, D, Nk, SEx, SExx, st);
+      if (D <= 64) return wmom_mfma<double, 16>(X, p, S, Bo, D, Nk, SEx, SExx, st);
     }
   }
   // samples per block: as many as fit a 48 KiB LDS image of [x | 1 | w] rows (at most 256)

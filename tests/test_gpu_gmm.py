@@ -197,7 +197,7 @@ def test_weighted_moments_mfma_fp32(K, D, N):
 
 
 @pytest.mark.parametrize("K,D,N", [(1, 32, 30001), (4, 16, 50000), (3, 2, 9000), (2, 21, 4099), (11, 16, 8191), (6, 24, 5000), (5, 1, 7000),
-                                   (7, 3, 6001), (4, 4, 100003)])
+                                   (7, 3, 6001), (4, 4, 100003), (3, 40, 5000), (5, 57, 4100), (2, 64, 4096)])
 def test_weighted_moments_mfma_fp64(K, D, N):
     """fp64 K4 on v_mfma_f64_16x16x4_f64 against an einsum, at the fp64 parity tolerance"""
     from pyvbmp_amd import ops
