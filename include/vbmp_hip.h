@@ -133,7 +133,7 @@ int vbmp_weighted_moments_f32(const float* X, const float* p, int64_t S, int64_t
  * thousand series already cover every SIMD) and one series per lane (more series). */
 #define VBMP_LDS_MAX_H 8        /* register-resident forms */
 #define VBMP_LDS_MAX_H_BLOCK 64 /* block-per-series form with LDS-resident matrices (8 < H; needs 5 H^2 words of LDS:
-                                   fp64 up to H = 62); larger H return VBMP_ERR_ARG and the caller composes the recursion */
+                                   fp64 up to H = 61); larger H return VBMP_ERR_ARG and the caller composes the recursion */
 #define VBMP_DECL_LDS_ARGS(SUF, REAL)                                                                         \
   typedef struct vbmp_lds_args_##SUF {                                                                     \
     int64_t T, S, NB;                                                                                      \

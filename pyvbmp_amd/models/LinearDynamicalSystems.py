@@ -319,7 +319,7 @@ class LinearDynamicalSystems():
         return out["Sigma_t_tp1"], out["Sigma_x0_x0"], out["mu_x0"].unsqueeze(-1), out["logZ"], None
 
     def _smoother_composed(self, T, lead, P_like, eta_like, res_like, cu1, cu2, cu3, x0_res):
-        """Same recursion as K9 for hidden dimensions beyond its kernels (h > 64, or fp64 with h > 62 whose matrices
+        """Same recursion as K9 for hidden dimensions beyond its kernels (h > 64, or fp64 with h > 61 whose matrices
         do not fit LDS): a host loop over time whose every step is batched over the series -- the inverses / logdets
         are K1 launches, the products rocBLAS GEMMs.  Launch-bound (about 40 launches per time step)."""
         h = self.hidden_dim

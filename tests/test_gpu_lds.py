@@ -224,13 +224,15 @@ def test_lds_block_form_matches_golden(golden, case, smoother_flags):
         assert_close(getattr(m, f), c["it1_" + f], 1e-9, what=f)
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-8), (torch.float32, 2e-2)])
-@pytest.mark.parametrize("h", [9, 12, 21, 52])
+@pytest.mark.parametrize("h,dtype,tol", [(9, torch.float64, 1e-8), (12, torch.float64, 1e-8), (21, torch.float64, 1e-8),
+                                         (52, torch.float64, 1e-8), (61, torch.float64, 1e-8), (12, torch.float32, 2e-2),
+                                         (52, torch.float32, 2e-2), (64, torch.float32, 2e-2)])
 def test_lds_block_form_vs_composed(h, dtype, tol, monkeypatch):
     """hidden dimensions beyond the register forms: the block-per-series kernel against the composed recursion
     (host loop of K1 launches + GEMMs), same model, same data"""
     from pyvbmp_amd import _lib
     from pyvbmp_amd.models import LinearDynamicalSystems
+    assert _lib.lds_block_fits(h, 8 if dtype == torch.float64 else 4)
     g = torch.Generator().manual_seed(h)
     y = lorenz(30, 5, g).to(dtype).to(DEV)
     torch.manual_seed(h)
