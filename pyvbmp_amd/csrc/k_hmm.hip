@@ -21,14 +21,22 @@ __device__ __forceinline__ void wsync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
-// log-sum-exp of v[0..K) (values in LDS, same for every lane of the chain); -inf safe
+// log-sum-exp of a K-vector held one entry per lane of the chain (lanes j >= K pass -inf): every lane exponentiates
+// its OWN entry once and the sum is read back from LDS (the fp64 exp is ~50 instructions; K of them per lane was the
+// bulk of this kernel).  buf: Kp words of the chain's LDS.  Same value on every lane; -inf safe.
 template <typename T>
-__device__ __forceinline__ T lse_vec(const T* v, int K) {
+__device__ __forceinline__ T lse_lanes(T mine, T* buf, int K, int j) {
+  buf[j] = mine;
+  wsync();
   T m = neg_inf<T>();
-  for (int i = 0; i < K; ++i) m = v[i] > m ? v[i] : m;
+  for (int i = 0; i < K; ++i) m = buf[i] > m ? buf[i] : m;
+  wsync();
   if (!(m > neg_inf<T>())) return m;
+  buf[j] = (j < K) ? exp(mine - m) : T(0);
+  wsync();
   T s = T(0);
-  for (int i = 0; i < K; ++i) s += exp(v[i] - m);
+  for (int i = 0; i < K; ++i) s += buf[i];
+  wsync();
   return m + log(s);
 }
 
@@ -82,10 +90,7 @@ __global__ __launch_bounds__(64) void k_hmm_fb(const T* __restrict__ logits, con
     wsync();
   }
   // logZ and normalisation (:81-83)
-  vec[j] = prev;
-  wsync();
-  const T lz = lse_vec<T>(vec, K);
-  wsync();
+  const T lz = lse_lanes<T>(prev, vec, K, j);
   T nxt = prev - lz;  // smoothed (= filtered) message at T-1
 
   // softmax with temperature of one message held one entry per lane (:100-101)
@@ -94,9 +99,13 @@ __global__ __launch_bounds__(64) void k_hmm_fb(const T* __restrict__ logits, con
     wsync();
     T mx = NI;
     for (int i = 0; i < K; ++i) mx = vec2[i] > mx ? vec2[i] : mx;
+    wsync();
+    const T e = (j < K) ? exp((mine - mx) / ptemp) : T(0);
+    vec2[j] = e;
+    wsync();
     T den = T(0);
-    for (int i = 0; i < K; ++i) den += exp((vec2[i] - mx) / ptemp);
-    if (live) pj[t * ts] = exp((mine - mx) / ptemp) / den;
+    for (int i = 0; i < K; ++i) den += vec2[i];
+    if (live) pj[t * ts] = e / den;
     wsync();
   };
   emit(Tn - 1, nxt);
@@ -125,22 +134,37 @@ __global__ __launch_bounds__(64) void k_hmm_fb(const T* __restrict__ logits, con
     for (int i = 0; i < Kp; ++i) {
       const T v = vec[i] + tr[i];
       xi[i] = (i < K && j < K && v > NI && cn > NI) ? (v - cn) + nxt : NI;
-      mat[i * Kp + j] = xi[i];
+    }
+    // ONE exponentiation per pair: e_ij = exp(xi_ij - G) with G the largest pair logit of the step.  Row sums of e
+    // give the new message, their total the normaliser, e / total the pair posterior (the reference's three
+    // log-sum-exps over the same K x K logits, :88-95, exponentiate each pair three times).
+    T cm = NI;
+#pragma unroll
+    for (int i = 0; i < Kp; ++i) cm = (i < K && xi[i] > cm) ? xi[i] : cm;
+    vec[j] = (j < K) ? cm : NI;
+    wsync();
+    T G = NI;
+    for (int i = 0; i < K; ++i) G = vec[i] > G ? vec[i] : G;
+    T e[Kp];
+#pragma unroll
+    for (int i = 0; i < Kp; ++i) {
+      e[i] = (i < K && j < K && xi[i] > NI) ? exp(xi[i] - G) : T(0);
+      mat[i * Kp + j] = e[i];
     }
     wsync();
-    // row j of xi -> new message entry j (as lane "i = j"), then the normaliser over all pairs
-    T rm = NI;
-    for (int jj = 0; jj < K; ++jj) rm = mat[j * Kp + jj] > rm ? mat[j * Kp + jj] : rm;
-    T rs = T(0);
-    for (int jj = 0; jj < K; ++jj) rs += (rm > NI) ? exp(mat[j * Kp + jj] - rm) : T(0);
-    const T newmsg = (j < K && rm > NI) ? rm + log(rs) : NI;
+    T rs = T(0);  // row j of e: unnormalised posterior of state j at the source time
+    for (int jj = 0; jj < K; ++jj) rs += mat[j * Kp + jj];
+    const T newmsg = (j < K && rs > T(0)) ? G + log(rs) : NI;
+    vec2[j] = (j < K) ? rs : T(0);
     wsync();
-    vec[j] = newmsg;
-    wsync();
-    const T all = lse_vec<T>(vec, K);
+    T total = T(0);
+    for (int i = 0; i < K; ++i) total += vec2[i];
+    const bool any = total > T(0);  // false only when every pair is forbidden
+    const T all = any ? G + log(total) : NI;
+    const T inv_total = any ? T(1) / total : T(0);
 #pragma unroll
     for (int i = 0; i < Kp; ++i)
-      if (i < K) acc[i] += (xi[i] > NI) ? exp(xi[i] - all) : T(0);
+      if (i < K) acc[i] += e[i] * inv_total;
     wsync();
     if (t >= 0) {
       nxt = newmsg;
