@@ -71,7 +71,7 @@ LDS_MAX_H_BLOCK = 64   # block-per-series form (LDS-resident matrices); also bou
 
 def lds_block_fits(h, itemsize):
     """does the block-per-series smoother's LDS image (five h x h matrices + vectors) fit the CU's 160 KB?"""
-    return (5 * h * (h | 1) + 16 * 72 + 8) * itemsize <= 160 * 1024
+    return (5 * h * (h | 1) + 24 * 72 + 8) * itemsize <= 160 * 1024
 
 
 def _sig_lds(T):
