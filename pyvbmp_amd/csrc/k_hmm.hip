@@ -21,25 +21,45 @@ __device__ __forceinline__ void wsync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
-// log-sum-exp of a K-vector held one entry per lane of the chain (lanes j >= K pass -inf): every lane exponentiates
-// its OWN entry once and the sum is read back from LDS (the fp64 exp is ~50 instructions; K of them per lane was the
-// bulk of this kernel).  buf: Kp words of the chain's LDS.  Same value on every lane; -inf safe.
-template <typename T>
-__device__ __forceinline__ T lse_lanes(T mine, T* buf, int K, int j) {
-  buf[j] = mine;
-  wsync();
-  T m = neg_inf<T>();
-  for (int i = 0; i < K; ++i) m = buf[i] > m ? buf[i] : m;
-  wsync();
-  if (!(m > neg_inf<T>())) return m;
-  buf[j] = (j < K) ? exp(mine - m) : T(0);
-  wsync();
-  T s = T(0);
-  for (int i = 0; i < K; ++i) s += buf[i];
-  wsync();
-  return m + log(s);
+// max / sum over the Kp lanes of a chain (butterfly through the cross-lane network: log2(Kp) steps instead of a K-step
+// loop of dependent LDS reads).  Same value on every lane of the chain.
+template <int Kp, typename T>
+__device__ __forceinline__ T grp_max(T v) {
+#pragma unroll
+  for (int off = Kp / 2; off > 0; off >>= 1) {
+    const T o = __shfl_xor(v, off, Kp);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+template <int Kp, typename T>
+__device__ __forceinline__ T grp_sum(T v) {
+#pragma unroll
+  for (int off = Kp / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, Kp);
+  return v;
 }
 
+// log-sum-exp of a K-vector held one entry per lane of the chain (lanes j >= K pass -inf): every lane exponentiates
+// its OWN entry once.  Same value on every lane; -inf safe.
+template <int Kp, typename T>
+__device__ __forceinline__ T lse_lanes(T mine) {
+  const T m = grp_max<Kp>(mine);
+  if (!(m > neg_inf<T>())) return m;
+  return m + log(grp_sum<Kp>(mine > neg_inf<T>() ? exp(mine - m) : T(0)));
+}
+
+// smallest column sum the probability-space step accepts (see k_hmm_fb): terms within 1e-17 of it are still normal
+template <typename T> __device__ __forceinline__ T hmm_safe_sum();
+template <> __device__ __forceinline__ double hmm_safe_sum<double>() { return 1e-130; }
+template <> __device__ __forceinline__ float hmm_safe_sum<float>() { return 1e-25f; }
+
+// Every step needs, for each target state j, L_j = log sum_i exp(x_i + tr_ij) over the K source states.  Taken
+// literally that is K exponentials per lane and step (K^2 per chain), which was ~90 % of this kernel in fp64.  Here a
+// step factors the sum as  exp(M) * sum_i a_i A_ij  with M = max_i x_i, a_i = exp(x_i - M) (ONE exponential per lane,
+// exchanged through LDS) and A = exp(tr) kept in registers, i.e. the scaled probability-space recursion -- but only
+// when that is exact to rounding: every column sum s_j must be >= hmm_safe_sum (then all terms that matter are
+// normal numbers) or exactly zero with no reachable source state.  A chain that fails the test in some step (logit
+// spreads of hundreds combined with forbidden transitions) takes the literal log-space form for that step.
 template <typename T, int Kp>
 __global__ __launch_bounds__(64) void k_hmm_fb(const T* __restrict__ logits, const T* __restrict__ trans,
                                                const T* __restrict__ init, int64_t Tn, int64_t C, int64_t NB, int K,
@@ -53,17 +73,43 @@ __global__ __launch_bounds__(64) void k_hmm_fb(const T* __restrict__ logits, con
   const bool live = (c < C) && (j < K);
   const int64_t cc = c < C ? c : C - 1;
   const int64_t b = cc % NB;
-  T* vec = smem + cl * (2 * Kp + Kp * Kp);  // [Kp] message exchange, [Kp] second vector, [Kp*Kp] pair logits
+  constexpr int LDM = Kp + 1;  // odd row stride: lane j reads ROW j of the pair matrix, a stride of Kp words would put all lanes on one bank
+  T* vec = smem + cl * (2 * Kp + Kp * LDM);  // [Kp] message exchange, [Kp] spare, [Kp][LDM] pair weights
   T* vec2 = vec + Kp;
   T* mat = vec2 + Kp;
   const T NI = neg_inf<T>();
-  // column j of the log transition matrix and entry j of the initial log probabilities
-  T tr[Kp], acc[Kp];
+  // column j of the transition matrix (A = exp(log transition); the log form is re-read from global memory by the rare
+  // log-space steps) and entry j of the initial log probabilities
+  auto TR = [&](int i) -> T { return (i < K && j < K) ? trans[(b * K + i) * K + j] : NI; };
+  T A[Kp], acc[Kp];
 #pragma unroll
   for (int i = 0; i < Kp; ++i) {
-    tr[i] = (i < K && j < K) ? trans[(b * K + i) * K + j] : NI;
+    A[i] = exp(TR(i));
     acc[i] = T(0);
   }
+  // do all lanes of my chain agree?
+  const unsigned long long grp = (Kp == 64) ? ~0ull : (((1ull << (Kp & 63)) - 1ull) << (cl * Kp));
+  auto chain_all = [&](bool ok) -> bool { return (__ballot(ok) & grp) == grp; };
+  // Column sums in probability space for the message x (entry j on lane j; lanes j >= K pass -inf).  Leaves a_i in
+  // vec[0..Kp) and returns M, s_j and whether the whole chain may use them.
+  auto col_sums = [&](T x, T& M, T& sj) -> bool {
+    M = grp_max<Kp>(x);
+    const T aj = (x > NI) ? exp(x - M) : T(0);
+    wsync();  // the previous readers of vec are done
+    vec[j] = aj;
+    wsync();
+    sj = T(0);
+#pragma unroll
+    for (int i = 0; i < Kp; ++i) sj += vec[i] * A[i];  // entries i >= K are 0 * 0: no guard, the reads go out together
+    const bool lost = !chain_all(!(x > NI && aj == T(0)));  // some finite entry of x underflowed against M
+    bool ok = sj >= hmm_safe_sum<T>();
+    if (!ok && sj == T(0)) {  // exact if no source state reaches j at all
+      bool reach = false;
+      for (int i = 0; i < K; ++i) reach = reach || (vec[i] > T(0) && TR(i) > NI);
+      ok = !reach && !lost;
+    }
+    return chain_all(ok || j >= K);
+  };
   const T in_j = (j < K) ? init[b * K + j] : NI;
   const T* lg = logits + cc * K + (j < K ? j : 0);  // element (t, c, j) at lg[t*C*K]
   T* pj = p + cc * K + (j < K ? j : 0);
@@ -71,100 +117,102 @@ __global__ __launch_bounds__(64) void k_hmm_fb(const T* __restrict__ logits, con
 
   // ---------------------------------------------------------------- forward (:77-80)
   T prev = in_j;
+  // a wave has few neighbours on its SIMD to hide a memory round trip behind (a few hundred chains make a few dozen
+  // waves): the observation logits of step t+1 are requested at the top of step t
+  T lg_next = lg[0];
   for (int64_t t = 0; t < Tn; ++t) {
-    vec[j] = prev;
-    wsync();
-    T m = NI;
-#pragma unroll
-    for (int i = 0; i < Kp; ++i) {
-      const T v = vec[i] + tr[i];
-      m = (i < K && v > m) ? v : m;
+    const T lg_t = lg_next;
+    lg_next = lg[(t + 1 < Tn ? t + 1 : t) * ts];
+    T M, sj;
+    if (col_sums(prev, M, sj)) {
+      prev = ((sj > T(0)) ? M + log(sj) : NI) + (j < K ? lg_t : T(0));
+    } else {
+      // literal log-space step
+      wsync();
+      vec[j] = prev;
+      wsync();
+      T m = NI;
+      for (int i = 0; i < K; ++i) {
+        const T v = vec[i] + TR(i);
+        m = v > m ? v : m;
+      }
+      T s = T(0);
+      for (int i = 0; i < K; ++i) s += (m > NI) ? exp(vec[i] + TR(i) - m) : T(0);
+      prev = ((m > NI) ? m + log(s) : NI) + (j < K ? lg_t : T(0));
     }
-    T s = T(0);
-#pragma unroll
-    for (int i = 0; i < Kp; ++i)
-      if (i < K) s += (m > NI) ? exp(vec[i] + tr[i] - m) : T(0);
-    prev = ((m > NI) ? m + log(s) : NI) + (j < K ? lg[t * ts] : T(0));
     if (j >= K) prev = NI;
     if (live) pj[t * ts] = prev;  // the p buffer holds the filtered logits until the backward sweep
     wsync();
   }
   // logZ and normalisation (:81-83)
-  const T lz = lse_lanes<T>(prev, vec, K, j);
+  const T lz = lse_lanes<Kp>(prev);
   T nxt = prev - lz;  // smoothed (= filtered) message at T-1
 
   // softmax with temperature of one message held one entry per lane (:100-101)
   auto emit = [&](int64_t t, T mine) {
-    vec2[j] = mine;
-    wsync();
-    T mx = NI;
-    for (int i = 0; i < K; ++i) mx = vec2[i] > mx ? vec2[i] : mx;
-    wsync();
+    const T mx = grp_max<Kp>(mine);
     const T e = (j < K) ? exp((mine - mx) / ptemp) : T(0);
-    vec2[j] = e;
-    wsync();
-    T den = T(0);
-    for (int i = 0; i < K; ++i) den += vec2[i];
+    const T den = grp_sum<Kp>(e);
     if (live) pj[t * ts] = e / den;
-    wsync();
   };
   emit(Tn - 1, nxt);
 
   // ---------------------------------------------------------------- backward smoothing (:85-98)
+  // the filtered logits of step t-1 are requested at the top of step t (the step writes slot t of p only)
+  T flt_next = (Tn >= 2) ? pj[(Tn - 2) * ts] : T(0);
   for (int64_t t = Tn - 2; t >= -1; --t) {
     // source message: filtered logits at t (normalised by logZ), or the initial distribution for the last step
-    const T src = (t >= 0) ? ((live ? pj[t * ts] : NI) - lz) : in_j;
-    vec[j] = (j < K) ? src : NI;
-    vec2[j] = nxt;
-    wsync();
-    // column j: temp[i] = src[i] + tr[i][j]; xi[i][j] = temp[i] - lse_i temp + nxt[j]
-    T m = NI;
+    const T flt = flt_next;
+    flt_next = pj[(t >= 1 ? t - 1 : 0) * ts];
+    const T src = (t >= 0) ? ((live ? flt : NI) - lz) : in_j;
+    const T xs = (j < K) ? src : NI;
+    // column j of the pair logits: xi[i][j] = (src[i] + tr[i][j] - lse_i(src[i] + tr[i][j])) + nxt[j]; the step needs
+    // e_ij = exp(xi_ij - Gs) for some common Gs: row sums of e give the new message, their total the normaliser,
+    // e / total the pair posterior (the reference's three log-sum-exps over the same K x K logits, :88-95).
+    T e[Kp], Gs, M, sj;
+    if (col_sums(xs, M, sj)) {
+      // probability space: exp(src_i + tr_ij - lse) = a_i A_ij / s_j, and Gs = max_j nxt_j keeps every e_ij <= 1
+      Gs = grp_max<Kp>(nxt);
+      const T u = (j < K && nxt > NI && sj > T(0)) ? exp(nxt - Gs) / sj : T(0);
 #pragma unroll
-    for (int i = 0; i < Kp; ++i) {
-      const T v = vec[i] + tr[i];
-      m = (i < K && v > m) ? v : m;
+      for (int i = 0; i < Kp; ++i) e[i] = (vec[i] * A[i]) * u;
+    } else {
+      // literal log-space step, ONE exponentiation per pair with Gs the largest pair logit
+      wsync();
+      vec[j] = xs;
+      wsync();
+      T m = NI;
+      for (int i = 0; i < K; ++i) {
+        const T v = vec[i] + TR(i);
+        m = v > m ? v : m;
+      }
+      T s = T(0);
+      for (int i = 0; i < K; ++i) s += (m > NI) ? exp(vec[i] + TR(i) - m) : T(0);
+      const T cn = (m > NI) ? m + log(s) : NI;
+      T xi[Kp], cm = NI;
+#pragma unroll
+      for (int i = 0; i < Kp; ++i) {
+        const T v = (i < K) ? vec[i] + TR(i) : NI;
+        xi[i] = (i < K && j < K && v > NI && cn > NI) ? (v - cn) + nxt : NI;
+        cm = xi[i] > cm ? xi[i] : cm;
+      }
+      Gs = grp_max<Kp>((j < K) ? cm : NI);
+#pragma unroll
+      for (int i = 0; i < Kp; ++i) e[i] = (xi[i] > NI) ? exp(xi[i] - Gs) : T(0);
     }
-    T s = T(0);
 #pragma unroll
-    for (int i = 0; i < Kp; ++i)
-      if (i < K) s += (m > NI) ? exp(vec[i] + tr[i] - m) : T(0);
-    const T cn = (m > NI) ? m + log(s) : NI;
-    T xi[Kp];
-#pragma unroll
-    for (int i = 0; i < Kp; ++i) {
-      const T v = vec[i] + tr[i];
-      xi[i] = (i < K && j < K && v > NI && cn > NI) ? (v - cn) + nxt : NI;
-    }
-    // ONE exponentiation per pair: e_ij = exp(xi_ij - G) with G the largest pair logit of the step.  Row sums of e
-    // give the new message, their total the normaliser, e / total the pair posterior (the reference's three
-    // log-sum-exps over the same K x K logits, :88-95, exponentiate each pair three times).
-    T cm = NI;
-#pragma unroll
-    for (int i = 0; i < Kp; ++i) cm = (i < K && xi[i] > cm) ? xi[i] : cm;
-    vec[j] = (j < K) ? cm : NI;
-    wsync();
-    T G = NI;
-    for (int i = 0; i < K; ++i) G = vec[i] > G ? vec[i] : G;
-    T e[Kp];
-#pragma unroll
-    for (int i = 0; i < Kp; ++i) {
-      e[i] = (i < K && j < K && xi[i] > NI) ? exp(xi[i] - G) : T(0);
-      mat[i * Kp + j] = e[i];
-    }
+    for (int i = 0; i < Kp; ++i) mat[i * LDM + j] = e[i];
     wsync();
     T rs = T(0);  // row j of e: unnormalised posterior of state j at the source time
-    for (int jj = 0; jj < K; ++jj) rs += mat[j * Kp + jj];
-    const T newmsg = (j < K && rs > T(0)) ? G + log(rs) : NI;
-    vec2[j] = (j < K) ? rs : T(0);
-    wsync();
-    T total = T(0);
-    for (int i = 0; i < K; ++i) total += vec2[i];
+#pragma unroll
+    for (int jj = 0; jj < Kp; ++jj) rs += mat[j * LDM + jj];  // padding entries are exact zeros
+    const T newmsg = (j < K && rs > T(0)) ? Gs + log(rs) : NI;
+    const T total = grp_sum<Kp>((j < K) ? rs : T(0));
     const bool any = total > T(0);  // false only when every pair is forbidden
-    const T all = any ? G + log(total) : NI;
+    const T all = any ? Gs + log(total) : NI;
     const T inv_total = any ? T(1) / total : T(0);
 #pragma unroll
-    for (int i = 0; i < Kp; ++i)
-      if (i < K) acc[i] += e[i] * inv_total;
+    for (int i = 0; i < Kp; ++i) acc[i] += e[i] * inv_total;
     wsync();
     if (t >= 0) {
       nxt = newmsg;
@@ -186,7 +234,7 @@ static int launch_hmm(const T* logits, const T* trans, const T* init, int64_t Tn
                       T* p, T* SEzz, T* SEz0, T* logZ, hipStream_t st) {
   constexpr int CPW = 64 / Kp;
   const int64_t blocks = (C + CPW - 1) / CPW;
-  const size_t smem = (size_t)CPW * (2 * Kp + Kp * Kp) * sizeof(T);
+  const size_t smem = (size_t)CPW * (2 * Kp + Kp * (Kp + 1)) * sizeof(T);
   hipLaunchKernelGGL((k_hmm_fb<T, Kp>), dim3((unsigned)blocks), dim3(64), smem, st, logits, trans, init, Tn, C, NB, K,
                      ptemp, p, SEzz, SEz0, logZ);
   return hipGetLastError() == hipSuccess ? 0 : VBMP_ERR_LAUNCH;

@@ -54,3 +54,30 @@ def test_hmm_forward_backward_vs_restatement(K, T, lead, batch, ptemp, dtype):
     assert_close(SEzz, rzz, tol, what="SEzz")
     assert_close(SEz0, rz0, tol, what="SEz0")
     assert_close(logZ, rlz, tol, what="logZ")
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("K,T,lead,scale,keep", [(4, 40, (9,), 400.0, 0.3), (25, 25, (6,), 250.0, 0.15), (8, 60, (33,), 1500.0, 0.5),
+                                                 (6, 30, (5,), 60.0, 0.3)])
+def test_hmm_extreme_logits_take_the_log_space_step(K, T, lead, scale, keep, dtype):
+    """observation logits whose spread (hundreds to thousands) underflows a scaled probability-space recursion, over a
+    sparse transition graph: the kernel must notice and fall back to the literal log-space step, chain by chain"""
+    from pyvbmp_amd import ops
+    g = torch.Generator().manual_seed(K * 11 + T)
+    logits = (scale * torch.randn((T,) + lead + (K,), generator=g, dtype=torch.float64)).to(dtype)
+    A = torch.rand(K, K, generator=g, dtype=torch.float64) + 0.05
+    mask = torch.rand(K, K, generator=g) < keep
+    mask |= torch.eye(K, dtype=torch.bool).roll(1, 0)  # a cycle keeps every state reachable
+    trans = torch.where(mask, A.log(), torch.full_like(A, -float("inf")))
+    trans = trans - torch.logsumexp(trans, -1, keepdim=True)
+    init = torch.log_softmax(torch.randn(K, generator=g, dtype=torch.float64), -1)
+    p, SEzz, SEz0, logZ = ops.hmm_forward_backward(logits.to(DEV), trans.to(dtype).to(DEV), init.to(dtype).to(DEV), (), 1.0)
+    rp, rzz, rz0, rlz = hmm_reference(logits.double(), trans.to(dtype).double(), init.to(dtype).double(), 1.0)
+    # fp32: the running log-likelihood reaches ~1e5 here, where one fp32 ulp is 8e-3 -- the message differences that
+    # decide an ambiguous state carry that absolute error whatever the recursion
+    tol = 1e-10 if dtype == torch.float64 else 5e-3
+    assert torch.isfinite(logZ).all()
+    assert_close(p, rp, tol, what="p")
+    assert_close(SEzz, rzz, tol, what="SEzz")
+    assert_close(SEz0, rz0, tol, what="SEz0")
+    assert_close(logZ, rlz, tol, what="logZ")
