@@ -13,6 +13,8 @@ namespace vbmp {
 
 template <typename T>
 __device__ __forceinline__ T neg_inf() { return -INFINITY; }
+template <typename T>
+__device__ __forceinline__ T nan_of() { return T(NAN); }
 
 // wave-level LDS ordering (LDS address space only)
 __device__ __forceinline__ void wsync() {
@@ -156,6 +158,7 @@ __global__ __launch_bounds__(64) void k_hmm_fb(const T* __restrict__ logits, con
     if (live) pj[t * ts] = e / den;
   };
   emit(Tn - 1, nxt);
+  T nxt_max = grp_max<Kp>(nxt);  // max_j nxt_j, carried along the backward sweep
 
   // ---------------------------------------------------------------- backward smoothing (:85-98)
   // the filtered logits of step t-1 are requested at the top of step t (the step writes slot t of p only)
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(64) void k_hmm_fb(const T* __restrict__ logits, con
     T e[Kp], Gs, M, sj;
     if (col_sums(xs, M, sj)) {
       // probability space: exp(src_i + tr_ij - lse) = a_i A_ij / s_j, and Gs = max_j nxt_j keeps every e_ij <= 1
-      Gs = grp_max<Kp>(nxt);
+      Gs = nxt_max;
       const T u = (j < K && nxt > NI && sj > T(0)) ? exp(nxt - Gs) / sj : T(0);
 #pragma unroll
       for (int i = 0; i < Kp; ++i) e[i] = (vec[i] * A[i]) * u;
@@ -206,20 +209,30 @@ __global__ __launch_bounds__(64) void k_hmm_fb(const T* __restrict__ logits, con
     T rs = T(0);  // row j of e: unnormalised posterior of state j at the source time
 #pragma unroll
     for (int jj = 0; jj < Kp; ++jj) rs += mat[j * LDM + jj];  // padding entries are exact zeros
-    const T newmsg = (j < K && rs > T(0)) ? Gs + log(rs) : NI;
-    const T total = grp_sum<Kp>((j < K) ? rs : T(0));
+    // exp(newmsg_j - max newmsg) = rs_j / max rs and sum_j of it = total / max rs: the softmax of the new message is
+    // rs / total, and max_j newmsg_j (the next step's Gs) is Gs + log(max rs) -- no further exponentials or reductions
+    const T rsv = (j < K) ? rs : T(0);
+    const T total = grp_sum<Kp>(rsv);
+    const T rsmax = grp_max<Kp>(rsv);
     const bool any = total > T(0);  // false only when every pair is forbidden
-    const T all = any ? Gs + log(total) : NI;
     const T inv_total = any ? T(1) / total : T(0);
 #pragma unroll
     for (int i = 0; i < Kp; ++i) acc[i] += e[i] * inv_total;
-    wsync();
+    const T soft = any ? rsv * inv_total : nan_of<T>();  // softmax of the new message (0/0 in the reference, too)
     if (t >= 0) {
-      nxt = newmsg;
-      emit(t, newmsg);
+      nxt = (rsv > T(0)) ? Gs + log(rsv) : NI;
+      nxt_max = any ? Gs + log(rsmax) : NI;
+      if (ptemp == T(1)) {
+        if (live) pj[t * ts] = soft;
+      } else {  // tempered softmax (:100-101)
+        const T et = (j < K) ? exp((nxt - nxt_max) / ptemp) : T(0);
+        const T den = grp_sum<Kp>(et);
+        if (live) pj[t * ts] = et / den;
+      }
     } else if (live) {
-      SEz0[cc * K + j] = exp(newmsg - all);  // softmax of the initial-state message (:96-97)
+      SEz0[cc * K + j] = soft;  // softmax of the initial-state message (:96-97)
     }
+    wsync();
   }
   if (live) {
 #pragma unroll
