@@ -23,22 +23,39 @@ __device__ __forceinline__ void wsync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
-// max / sum over the Kp lanes of a chain (butterfly through the cross-lane network: log2(Kp) steps instead of a K-step
-// loop of dependent LDS reads).  Same value on every lane of the chain.
-template <int Kp, typename T>
-__device__ __forceinline__ T grp_max(T v) {
-#pragma unroll
-  for (int off = Kp / 2; off > 0; off >>= 1) {
-    const T o = __shfl_xor(v, off, Kp);
-    v = o > v ? o : v;
-  }
+// max / sum over the Kp lanes of a chain as an xor butterfly (log2(Kp) steps instead of a K-step loop of dependent
+// LDS reads; every pair is combined symmetrically, so all lanes of the chain end with the SAME bits).  The four steps
+// inside a 16-lane row are DPP moves (quad_perm, row_half_mirror, row_mirror: ~10 cycles each); only the steps across
+// rows (Kp = 32, 64) go through the LDS crossbar (ds_bpermute, ~10x that).
+template <int CTRL>
+__device__ __forceinline__ float dpp_xchg(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_xchg(double v) {
+  union { double d; int i[2]; } a, r;
+  a.d = v;
+  r.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], CTRL, 0xf, 0xf, true);
+  r.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], CTRL, 0xf, 0xf, true);
+  return r.d;
+}
+template <int Kp, typename T, typename F>
+__device__ __forceinline__ T grp_butterfly(T v, F op) {
+  if constexpr (Kp >= 2) v = op(v, dpp_xchg<0xB1>(v));   // quad_perm:[1,0,3,2]  (lane ^ 1)
+  if constexpr (Kp >= 4) v = op(v, dpp_xchg<0x4E>(v));   // quad_perm:[2,3,0,1]  (lane ^ 2)
+  if constexpr (Kp >= 8) v = op(v, dpp_xchg<0x141>(v));  // row_half_mirror: 7 - lane, = lane ^ 4 once quads agree
+  if constexpr (Kp >= 16) v = op(v, dpp_xchg<0x140>(v)); // row_mirror: 15 - lane, = lane ^ 8 once octets agree
+  if constexpr (Kp >= 32) v = op(v, __shfl_xor(v, 16, 64));
+  if constexpr (Kp >= 64) v = op(v, __shfl_xor(v, 32, 64));
   return v;
 }
 template <int Kp, typename T>
+__device__ __forceinline__ T grp_max(T v) {
+  return grp_butterfly<Kp>(v, [](T a, T b) { return b > a ? b : a; });
+}
+template <int Kp, typename T>
 __device__ __forceinline__ T grp_sum(T v) {
-#pragma unroll
-  for (int off = Kp / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, Kp);
-  return v;
+  return grp_butterfly<Kp>(v, [](T a, T b) { return a + b; });
 }
 
 // log-sum-exp of a K-vector held one entry per lane of the chain (lanes j >= K pass -inf): every lane exponentiates
