@@ -1,9 +1,9 @@
-// K11: log-space forward-backward of a discrete HMM (ref models/HMM.py:72-105), the role chain of
-// DynamicMarkovBlanketDiscovery.  One launch replaces the reference's two Python loops over T.
-// A chain (one series x observable) is owned by Kp lanes (Kp = K padded to a power of two); lane j keeps
-// column j of the log transition matrix, of the pair-statistic accumulator SEzz and entry j of the message in
-// registers; the K-vectors / K x K pair logits that must cross lanes go through a small per-chain LDS buffer.
-// Time is sequential inside the kernel.  gfx950 only.
+// K11: forward-backward of a discrete HMM with log-space inputs and outputs (ref models/HMM.py:72-105), the role chain
+// of DynamicMarkovBlanketDiscovery.  One launch replaces the reference's two Python loops over T.
+// A chain (one series x observable) is owned by Kp lanes (Kp = K padded to a power of two); lane j keeps column j of
+// the transition matrix, of the pair-statistic accumulator SEzz and entry j of the message in registers; K-vectors
+// that every lane must see and the K x K pair weights (written by columns, summed by rows) go through a small
+// per-chain LDS buffer, scalar reductions through DPP butterflies.  Time is sequential inside the kernel.  gfx950 only.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "vbmp_dispatch.h"
@@ -93,9 +93,8 @@ __global__ __launch_bounds__(64) void k_hmm_fb(const T* __restrict__ logits, con
   const int64_t cc = c < C ? c : C - 1;
   const int64_t b = cc % NB;
   constexpr int LDM = Kp + 1;  // odd row stride: lane j reads ROW j of the pair matrix, a stride of Kp words would put all lanes on one bank
-  T* vec = smem + cl * (2 * Kp + Kp * LDM);  // [Kp] message exchange, [Kp] spare, [Kp][LDM] pair weights
-  T* vec2 = vec + Kp;
-  T* mat = vec2 + Kp;
+  T* vec = smem + cl * (Kp + Kp * LDM);  // [Kp] message exchange, [Kp][LDM] pair weights
+  T* mat = vec + Kp;
   const T NI = neg_inf<T>();
   // column j of the transition matrix (A = exp(log transition); the log form is re-read from global memory by the rare
   // log-space steps) and entry j of the initial log probabilities
@@ -121,13 +120,13 @@ __global__ __launch_bounds__(64) void k_hmm_fb(const T* __restrict__ logits, con
 #pragma unroll
     for (int i = 0; i < Kp; ++i) sj += vec[i] * A[i];  // entries i >= K are 0 * 0: no guard, the reads go out together
     const bool lost = !chain_all(!(x > NI && aj == T(0)));  // some finite entry of x underflowed against M
-    bool ok = sj >= hmm_safe_sum<T>();
+    bool ok = sj >= hmm_safe_sum<T>() || j >= K;  // padding lanes never vote (and never walk the loop below)
     if (!ok && sj == T(0)) {  // exact if no source state reaches j at all
       bool reach = false;
       for (int i = 0; i < K; ++i) reach = reach || (vec[i] > T(0) && TR(i) > NI);
       ok = !reach && !lost;
     }
-    return chain_all(ok || j >= K);
+    return chain_all(ok);
   };
   const T in_j = (j < K) ? init[b * K + j] : NI;
   const T* lg = logits + cc * K + (j < K ? j : 0);  // element (t, c, j) at lg[t*C*K]
@@ -264,7 +263,7 @@ static int launch_hmm(const T* logits, const T* trans, const T* init, int64_t Tn
                       T* p, T* SEzz, T* SEz0, T* logZ, hipStream_t st) {
   constexpr int CPW = 64 / Kp;
   const int64_t blocks = (C + CPW - 1) / CPW;
-  const size_t smem = (size_t)CPW * (2 * Kp + Kp * (Kp + 1)) * sizeof(T);
+  const size_t smem = (size_t)CPW * (Kp + Kp * (Kp + 1)) * sizeof(T);
   hipLaunchKernelGGL((k_hmm_fb<T, Kp>), dim3((unsigned)blocks), dim3(64), smem, st, logits, trans, init, Tn, C, NB, K,
                      ptemp, p, SEzz, SEz0, logZ);
   return hipGetLastError() == hipSuccess ? 0 : VBMP_ERR_LAUNCH;

@@ -9,7 +9,7 @@ if len(sys.argv) > 1:  # A/B against another build of the library
 
 dev = torch.device("cuda")
 for dt in (torch.float64, torch.float32):
-    for (T, C, K) in ((100, 240, 25), (400, 64, 4), (1000, 4096, 8)):
+    for (T, C, K) in ((100, 240, 25), (400, 64, 4), (1000, 4096, 8), (100, 240, 16), (100, 240, 12), (100, 240, 32), (100, 240, 40)):
         torch.manual_seed(0)
         lg = torch.randn(T, C, K, dtype=dt, device=dev) * 3
         tr = torch.log_softmax(torch.randn(K, K, dtype=dt, device=dev), -1)
