@@ -81,3 +81,26 @@ def test_hmm_extreme_logits_take_the_log_space_step(K, T, lead, scale, keep, dty
     assert_close(SEzz, rzz, tol, what="SEzz")
     assert_close(SEz0, rz0, tol, what="SEz0")
     assert_close(logZ, rlz, tol, what="logZ")
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_hmm_revived_state_needs_the_log_space_step(dtype):
+    """state 2 is reachable only through state 1, whose filtered weight is exp(-1000) of the leader's (zero in any
+    scaled probability-space recursion); the next observation then favours state 2 by 3000 nats.  The posterior must
+    follow the path 1 -> 2, which only a log-space step at that time can see."""
+    from pyvbmp_amd import ops
+    ninf = -float("inf")
+    trans = torch.tensor([[0.0, ninf, ninf], [ninf, -0.7, -0.7], [ninf, ninf, 0.0]], dtype=torch.float64)
+    init = torch.log(torch.tensor([0.5, 0.5, 1e-300], dtype=torch.float64))
+    logits = torch.zeros(6, 2, 3, dtype=torch.float64)
+    logits[0, :, 0] = 1000.0   # state 0 leads state 1 by 1000 nats after the first step
+    logits[2, :, 2] = 3000.0   # ... and state 2 is what the third observation wants
+    logits[4, 1, 1] = 5.0
+    p, SEzz, SEz0, logZ = ops.hmm_forward_backward(logits.to(dtype).to(DEV), trans.to(dtype).to(DEV), init.to(dtype).to(DEV), (), 1.0)
+    rp, rzz, rz0, rlz = hmm_reference(logits, trans, init.to(dtype).double(), 1.0)
+    assert rp[3, 0, 2] > 0.99  # the reference ends up in state 2
+    tol = 1e-10 if dtype == torch.float64 else TOL32 * 5
+    assert_close(p, rp, tol, what="p")
+    assert_close(SEzz, rzz, tol, what="SEzz")
+    assert_close(SEz0, rz0, tol, what="SEz0")
+    assert_close(logZ, rlz, tol, what="logZ")
