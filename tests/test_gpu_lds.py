@@ -248,3 +248,34 @@ def test_lds_block_form_vs_composed(h, dtype, tol, monkeypatch):
         assert_close(got[f], getattr(m.px, f), tol, what=f)
     for f in ("SE_x_x", "SE_x_xpu", "logZ"):
         assert_close(got[f], getattr(m, f), tol, what=f)
+
+
+@pytest.mark.parametrize("form", ["rows", "lanes", "block"])
+@pytest.mark.parametrize("T", [1, 2, 3])
+def test_lds_smoother_short_series(T, form, smoother_form, smoother_flags):
+    """one, two and three time steps: the sweeps' peeled first / last steps and the smoothed covariance that every
+    device form carries over to the following step (the first pending one is the filtered posterior of the last step)"""
+    from oracle import lds as olds
+    from oracle import mnw as omnw
+    from oracle import niw as oniw
+    from pyvbmp_amd.models import LinearDynamicalSystems
+    if form == "block":
+        smoother_flags(0x200)
+    else:
+        smoother_form(form)
+    h, S = 3, 6
+    g = torch.Generator().manual_seed(7 + T)
+    y = lorenz(max(T, 4), S, g)[:T]
+    m = LinearDynamicalSystems((6,), h, latent_noise='shared', device=DEV, dtype=torch.float64)
+    x0 = oniw.niw_new((h,), (), mu_init=m.x0.mu.cpu())
+    A = omnw.mnw_new((h, h + 1), (), mu_init=m.A.mu.cpu())
+    obs = omnw.mnw_new((6, h + 1), (), mu_init=m.obs_model.mu.cpu())
+    yy, uu, rr = m.reshape_inputs(y.to(DEV))
+    m.update_latents(yy, uu, rr)
+    yo, uo, ro = olds.reshape_inputs(y, None, None, (6,), 1, 1)
+    sm = olds.smoother(olds.latent_parms(A, h), x0, h, yo, uo, ro, obs, 0)
+    for f in ("mu", "Sigma", "invSigma", "invSigmamu"):
+        assert_close(getattr(m.px, f), sm[f], 1e-9, what=f)
+    st = olds.latent_stats(sm, yo, uo, ro, (6,), 1, 1, (), 0)
+    for f in ("logZ", "SE_x_x", "SE_x_xpu", "SE_x0_x0"):
+        assert_close(getattr(m, f), st[f], 1e-9, what=f)
