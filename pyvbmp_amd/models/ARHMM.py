@@ -3,6 +3,7 @@ reference's models/ARHMM.py:13-91).  ARHMM_prXRY is the role model of DynamicMar
 (a Gaussian message), observed regressors r and observed outputs y."""
 import torch
 
+from .._common import shared_matvec, shared_weighted_sum
 from ..dists.Delta import Delta
 from ..dists.MultivariateNormal_vector_format import MultivariateNormal_vector_format
 from ..transforms.MatrixNormalWishart import MatrixNormalWishart
@@ -24,7 +25,9 @@ def _role_average(p, P, eta, Res):
     if p is None:
         return P, eta, Res
     w = _weight(p, 2)
-    return (P * w).sum(-3), (eta * w).sum(-3), (Res * p).sum(-1)
+    # a precision shared by all samples (it depends on the parameters only) is averaged as one GEMM over the states
+    Pbar = shared_weighted_sum(P, p) if P.dim() == 3 and p.dim() > 1 else (P * w).sum(-3)
+    return Pbar, (eta * w).sum(-3), (Res * p).sum(-1)
 
 
 class ARHMM(HMM):
@@ -93,7 +96,7 @@ class ARHMM_prXRY(HMM):
         P_xr, eta_xr, Res = self.obs_dist.Elog_like_X(YR[0])
         p1, R = self.p1, YR[1]
         P = P_xr[..., :p1, :p1]
-        eta = eta_xr[..., :p1, :] - P_xr[..., :p1, p1:] @ R
+        eta = eta_xr[..., :p1, :] - shared_matvec(P_xr[..., :p1, p1:], R)
         Res = Res - 0.5 * (P_xr[..., p1:, p1:] * (R * R.transpose(-2, -1))).sum((-1, -2))
         Res = Res + (eta_xr[..., p1:, :] * R).sum((-1, -2))
         return _role_average(self.p, P, eta, Res)

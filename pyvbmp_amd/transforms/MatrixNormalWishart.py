@@ -16,7 +16,7 @@ import math
 import torch
 
 from .. import ops
-from .._common import as_param, resolve
+from .._common import as_param, resolve, shared_matvec
 from ..dists.MultivariateNormal_vector_format import MultivariateNormal_vector_format
 from ..dists.Wishart import Wishart
 from ..utils.matrix_utils import matrix_utils
@@ -312,8 +312,8 @@ class MatrixNormalWishart():
         H, Gt = self.EXTinvUX(), self.EXTinvU()
         Residual = self._residual_y(Y)
         if self.pad_X:
-            return H[..., :-1, :-1], Gt[..., :-1, :] @ Y - H[..., :-1, -1:], Residual - 0.5 * H[..., -1, -1]
-        return H, Gt @ Y, Residual
+            return H[..., :-1, :-1], shared_matvec(Gt[..., :-1, :], Y) - H[..., :-1, -1:], Residual - 0.5 * H[..., -1, -1]
+        return H, shared_matvec(Gt, Y), Residual
 
     def _joint_blocks(self, pY, bias_sign):
         R, G, H = self.EinvSigma(), self.EinvUX(), self.EXTinvUX()
