@@ -26,11 +26,11 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     torch.cuda.synchronize()
 rows = []
 for e in prof.key_averages(group_by_input_shape=True):
-    if e.key in ("aten::mm", "aten::bmm", "aten::addmm", "aten::baddbmm", "aten::mul", "aten::sum", "aten::matmul", "aten::add", "aten::copy_", "aten::cumsum"):
+    if True:
         t = getattr(e, "device_time_total", None)
         if t is None:
             t = e.cuda_time_total
         rows.append((t, e.count, e.key, str(e.input_shapes)[:150]))
 rows.sort(reverse=True)
-for t, c, k, sh in rows[:28]:
+for t, c, k, sh in rows[:int(os.environ.get('TOPN', '34'))]:
     print(f"{t / 1e3:8.3f} ms {c:4d}x {k:14s} {sh}")
