@@ -127,3 +127,37 @@ def test_mnw_masks_golden(golden, case):
     _check(m, c, "raw2_")
     assert_close(m.KLqprior(), c["KLqprior"], what="KL")
     assert_close(m.Elog_like(X, Y), c["Elog_like"], what="Elog_like")
+
+
+@pytest.mark.parametrize("keep,batch", [(0.2, ()), (0.8, ()), (0.3, (3,)), (0.7, (2,))])
+def test_mnw_masked_mean_primal_and_dual(keep, batch):
+    """constrained posterior mean for sparse masks (fewer free than zeroed entries: the primal system on the free
+    entries is solved) and dense ones (the reference's dual system on the zeroed entries), against the oracle, which
+    always takes the reference's route (LU solve of the dual system)"""
+    from oracle import mnw as omnw
+    from pyvbmp_amd.transforms import MatrixNormalWishart
+    n, p, N = 7, 9, 200
+    g = torch.Generator().manual_seed(int(keep * 100) + len(batch))
+    mask = torch.rand(n, p, generator=g) < keep
+    mask[torch.arange(n), torch.arange(n)] = True  # every row keeps an entry
+    m = MatrixNormalWishart((n, p), batch, mask=mask.to(DEV), device=DEV, dtype=torch.float64)
+    (zi, _), (fi, _) = m._mask_entries()
+    assert (fi.numel() <= zi.numel()) == (keep < 0.5)  # the case really takes the branch it is meant for
+    st = omnw.mnw_new((n, p), batch, mu_init=m.mu.cpu(), mask=mask)
+    for lr in (1.0, 0.6):
+        X = torch.randn((N,) + batch + (p, 1), generator=g, dtype=torch.float64)
+        Wt = torch.randn(n, p, generator=g, dtype=torch.float64) * mask
+        # noise large enough that the reference's noise update (SEyy - mu invV mu', not exact for a constrained mean)
+        # stays positive definite -- otherwise the second round would solve an indefinite system on both sides
+        Y = Wt @ X + 2.0 * torch.randn((N,) + batch + (n, 1), generator=g, dtype=torch.float64)
+        SExx = (X @ X.transpose(-2, -1)).sum(0)
+        SEyx = (Y @ X.transpose(-2, -1)).sum(0)
+        SEyy = (Y @ Y.transpose(-2, -1)).sum(0)
+        Nn = torch.full(batch, float(N), dtype=torch.float64)
+        assert torch.linalg.eigvalsh(omnw._noise_expect(st["W"])["EinvSigma"]).min() > 0
+        m.ss_update(SExx.to(DEV), SEyx.to(DEV), SEyy.to(DEV), Nn.to(DEV), lr=lr)
+        st = omnw.mnw_ss_update(st, SExx, SEyx, SEyy, Nn, lr=lr)
+        assert_close(m.mu, st["mu"], 1e-10, what=f"mu lr={lr}")
+        assert_close(m.invV, st["invV"], 1e-10, what="invV")
+        assert_close(m.invU.invU, st["W"]["invU"], 1e-10, what="invU")
+        assert (m.mu[..., ~mask.to(DEV)] == 0).all()
