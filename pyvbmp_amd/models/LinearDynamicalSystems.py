@@ -29,6 +29,45 @@ def _T(a):
     return a.transpose(-2, -1)
 
 
+def _time_constant(x):
+    return x.shape[0] == 1 or x.stride(0) == 0
+
+
+class _TimeSums:
+    """sum_t a[t] b[t]' over the time axis for the statistics of update_latents.  An operand that does not depend on
+    time (the appended ones of the control / regression inputs, or their stand-ins when there are none: stride 0)
+    factors out of the sum, so those moments need the time sum of the OTHER operand only -- computed once per operand
+    and shared (the default model needs sum_t mu_t for three of its eight moments) -- instead of a K10 pass over both;
+    everything else is one K10 launch (ops.tsum_outer)."""
+
+    def __init__(self):
+        self._sums = {}
+
+    def _window(self, x, frm, steps):
+        """sum_{t < steps} x[t + frm]"""
+        if _time_constant(x):
+            return steps * x[0]
+        hit = self._sums.get(id(x))
+        if hit is None:
+            hit = self._sums[id(x)] = (x, x.sum(0))  # the operand is kept alive with its sum
+        s = hit[1]
+        for t in list(range(frm)) + list(range(frm + steps, x.shape[0])):
+            s = s - x[t]
+        return s
+
+    def __call__(self, a, b, M=None, a_from=0, b_from=0, steps=None):
+        T = max(a.shape[0], b.shape[0])
+        if steps is None:
+            steps = T - max(a_from, b_from)
+        ca, cb = _time_constant(a), _time_constant(b)
+        if M is not None or not (ca or cb) or T - steps > 4:
+            return ops.tsum_outer(a, b, M=M, a_from=a_from, b_from=b_from, steps=steps)
+        A = a[0] if ca else self._window(a, a_from, steps)
+        B = b[0] if cb else self._window(b, b_from, steps)
+        out = A.unsqueeze(-1) * B.unsqueeze(-2)
+        return steps * out if (ca and cb) else out
+
+
 class LinearDynamicalSystems():
     def __init__(self, obs_shape, hidden_dim, control_dim=0, regression_dim=0, obs_model=None,
                  latent_noise='independent', batch_shape=(), A_mask=None, B_mask=None, device=None, dtype=None):
@@ -78,7 +117,9 @@ class LinearDynamicalSystems():
         """vector format, appended ones, optional expansion to the batch (ref :56-83)"""
         sample_shape = tuple(y.shape[:y.ndim - len(self.obs_shape)])
         y = y.unsqueeze(-1)
-        one = torch.ones((), device=y.device, dtype=y.dtype)
+        one = getattr(self, "_one", None)  # one tensor for all calls: the stand-in inputs keep their address, which is
+        if one is None or one.device != y.device or one.dtype != y.dtype:  # what the data-moment cache keys on
+            one = self._one = torch.ones((), device=y.device, dtype=y.dtype)
         if u is None:
             u = one.expand(sample_shape + (self.control_dim, 1))
         else:
@@ -170,6 +211,17 @@ class LinearDynamicalSystems():
         self.logZ = red[len(names)]
         return red[len(names) + 1:]
 
+    def _data_moment(self, ts, name, a, b):
+        """sum_t a[t] b[t]' of two DATA tensors, remembered for as long as update_latents is called on the same,
+        unmodified storage (the key holds address, version counter and layout; the operands are kept alive with the
+        result so that the address cannot be handed to another tensor meanwhile)"""
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride())) for t in (a, b))
+        store = self.__dict__.setdefault("_data_moments", {})
+        hit = store.get(name)
+        if hit is None or hit[0] != key:
+            hit = store[name] = (key, (a, b), ts(a, b))
+        return hit[2]
+
     def update_latents(self, y, u, r, p=None, lr=1.0):
         """E-step: smoothed posteriors px, logZ and the time-integrated statistics (ref :156-216)."""
         if self.px is None:
@@ -180,7 +232,7 @@ class LinearDynamicalSystems():
         Tn = y.shape[0]
         mu, Sig = self.px.mu, self.px.Sigma
         mv, yv, uv, rv = mu.squeeze(-1), y.squeeze(-1), u.squeeze(-1), r.squeeze(-1)
-        ts = ops.tsum_outer
+        ts = _TimeSums()
         SE_x0_x0 = Sigma_x0_x0 + SE_x0 @ _T(SE_x0)
         sum_xx, sum_xpx = getattr(self, "_time_sums", (None, None))
         SE_x_x = sum_xx if sum_xx is not None else ts(mv, mv, M=Sig)
@@ -191,10 +243,11 @@ class LinearDynamicalSystems():
             + SE_x0 @ _T(mu[0]) + Sigma_t_tp1[-1]
         SE_x_r = ts(mv, rv)
         SE_x_y = ts(mv, yv)
-        SE_u_u = ts(uv, uv)
-        SE_r_r = ts(rv, rv)
-        SE_y_y = ts(yv, yv)
-        SE_y_r = ts(yv, rv)
+        # moments of the data alone do not change between VB iterations on the same (unmodified) tensors
+        SE_u_u = self._data_moment(ts, "uu", uv, uv)
+        SE_r_r = self._data_moment(ts, "rr", rv, rv)
+        SE_y_y = self._data_moment(ts, "yy", yv, yv)
+        SE_y_r = self._data_moment(ts, "yr", yv, rv)
 
         sample_shape = tuple(y.shape[1:y.ndim - self.event_dim - self.batch_dim - 1])
         lead = sample_shape + self.batch_shape
