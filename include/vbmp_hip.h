@@ -215,6 +215,16 @@ int vbmp_hmm_forward_backward_f32(const float* logits, const float* trans, const
 int vbmp_weighted_matsum_f64(const double* C, const double* w, int64_t S, int64_t E, double* out, void* stream);
 int vbmp_weighted_matsum_f32(const float* C, const float* w, int64_t S, int64_t E, float* out, void* stream);
 
+/* K12 -- one shared small matrix applied to many rows: out[s,:] = M x[s,:] + c, s < S (the likelihood message
+ * eta = E[A' R] y of every observation, MatrixNormalWishart.Elog_like_X, transforms/MatrixNormalWishart.py:251-261, on
+ * the (time x series) rows of the LDS E-step).  X dense (S,k); M dense (n,k); c (n) or NULL; out dense (S,n).
+ * 1 <= k, n <= VBMP_ROWS_MAX_DIM. */
+#define VBMP_ROWS_MAX_DIM 64
+int vbmp_rows_affine_f64(const double* X, int64_t S, int k, const double* M, const double* c, int n, double* out,
+                         void* stream);
+int vbmp_rows_affine_f32(const float* X, int64_t S, int k, const float* M, const float* c, int n, float* out,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,13 @@ def shared_matvec(G, Y):
     samples*batch tiny matrix-vector products a broadcasting `@` is lowered to (600 000 of them, 2 ms, for the role
     emissions of the flocking DMBD).  Anything that does not have this shape goes to `@` unchanged."""
     nb = G.dim() - 2
+    if nb == 0 and Y.dim() > 2 and Y.shape[-1] == 1 and Y.is_cuda and max(G.shape) <= 64 and Y.numel() >= 65536 * G.shape[-1]:
+        # ONE matrix, very many vectors (the observation messages of an LDS E-step: 4e6 rows of 6): the library GEMM for
+        # such a shape runs at a tenth of the memory bandwidth; K12 streams the rows once
+        from . import ops
+        return ops.rows_affine(Y.reshape(-1, G.shape[-1]), G).reshape(tuple(Y.shape[:-2]) + (G.shape[-2], 1))
+    if nb == 0 and Y.dim() > 2 and Y.shape[-1] == 1:
+        return (Y.squeeze(-1) @ G.transpose(0, 1)).unsqueeze(-1)  # fewer rows: one row-major GEMM
     if nb < 1 or Y.dim() < G.dim() or Y.shape[-1] != 1 or any(s != 1 for s in Y.shape[-2 - nb:-2]):
         return G @ Y
     sample = tuple(Y.shape[:-2 - nb])

@@ -105,6 +105,11 @@ def _sig_matsum(T):
     return [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr]
 
 
+def _sig_rows(T):
+    # X, S, k, M, c, n, out, stream
+    return [_c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr]
+
+
 # symbol -> argtypes builder.  Every symbol declared in include/vbmp_hip.h appears here
 # (tests/test_cabi.py cross-checks the header against this table and against the .so).
 SYMBOLS = {
@@ -119,6 +124,7 @@ SYMBOLS = {
     "vbmp_mnw_message": _sig_mnw_msg,
     "vbmp_hmm_forward_backward": _sig_hmm,
     "vbmp_weighted_matsum": _sig_matsum,
+    "vbmp_rows_affine": _sig_rows,
 }
 DTYPES = {"f64": (torch.float64, ctypes.c_double), "f32": (torch.float32, ctypes.c_float)}
 

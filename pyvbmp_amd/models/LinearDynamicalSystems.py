@@ -16,7 +16,7 @@ import math
 import torch
 
 from .. import ops
-from .._common import resolve
+from .._common import resolve, shared_matvec
 from ..dists.MultivariateNormal_vector_format import MultivariateNormal_vector_format
 from ..dists.NormalInverseWishart import NormalInverseWishart
 from ..transforms.MatrixNormalGamma import MatrixNormalGamma
@@ -313,9 +313,10 @@ class LinearDynamicalSystems():
         invSigma_t_t = self.BTRB_xp_xp
         Rc = self._compact(R, 2)  # the regressor is usually the constant bias column: keep it unexpanded
         if self.BTR_xp_y.ndim == 2:
-            # one shared (h x obs) map applied to T*S observations: a tall-skinny row-major GEMM (Y2 @ M^T) instead of a
-            # batched (h x obs)@(obs x 1) product per (t, series), which rocBLAS runs an order of magnitude slower
-            invSigmamu_t = (Y.squeeze(-1) @ _T(self.BTR_xp_y)).unsqueeze(-1) - self.BTRB_xp_r @ Rc
+            # one shared (h x obs) map applied to T*S observations: K12 streams the rows once when there are many (a
+            # broadcast `@` is a batched (h x obs)@(obs x 1) product per (t, series), and even the tall-skinny row-major
+            # GEMM Y2 @ M^T reaches a tenth of the memory bandwidth at 4e6 x 6 by 6 x 6)
+            invSigmamu_t = shared_matvec(self.BTR_xp_y, Y) - self.BTRB_xp_r @ Rc
         else:
             invSigmamu_t = self.BTR_xp_y @ Y - self.BTRB_xp_r @ Rc
         # -1/2 y' invR y + y' (BTR_r_y' r) + const as ONE quadratic-form launch (K3a) instead of per-(t, series) bmm

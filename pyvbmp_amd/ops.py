@@ -459,3 +459,23 @@ def weighted_matsum(C, w=None):
         fn = getattr(lib, "vbmp_weighted_matsum_" + L.suffix(dt))
         L.call(fn, "vbmp_weighted_matsum", L.ptr(Cc), L.ptr(wc), S, E, L.ptr(out), L.stream_ptr(dev))
     return out.reshape(inner)
+
+
+ROWS_MAX_DIM = 64
+
+
+def rows_affine(X, M, c=None):
+    """K12: out[s] = M @ X[s] (+ c) for X (S, k) dense, M (n, k), c (n,) or None; returns (S, n)."""
+    dev = L.require_device(X, M, c)
+    lib = L.load()
+    dt = X.dtype
+    Xc, Mc = X.contiguous(), M.to(dt).contiguous()
+    cc = None if c is None else c.to(dt).contiguous()
+    S, k = Xc.shape
+    n = Mc.shape[0]
+    assert Mc.shape == (n, k) and (cc is None or cc.shape == (n,))
+    out = torch.empty(S, n, dtype=dt, device=dev)
+    if S > 0:
+        fn = getattr(lib, "vbmp_rows_affine_" + L.suffix(dt))
+        L.call(fn, "vbmp_rows_affine", L.ptr(Xc), S, k, L.ptr(Mc), L.ptr(cc), n, L.ptr(out), L.stream_ptr(dev))
+    return out

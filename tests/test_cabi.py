@@ -49,6 +49,10 @@ def test_bad_arguments_are_rejected_without_a_gpu(lib):
     assert lib.vbmp_spd_inv_logdet_f64(null, 16, null, null, 5, 4, null, null) == -1
     assert lib.vbmp_spd_inv_logdet_f64(null, 16, null, null, 0, 4, null, null) == 0  # empty batch: nothing to do
     assert lib.vbmp_spd_inv_logdet_f32(ctypes.c_void_p(16), 16, ctypes.c_void_p(16), null, 5, 65, null, null) == -1
+    some = ctypes.c_void_p(16)
+    assert lib.vbmp_rows_affine_f64(some, 10, 65, some, null, 3, some, null) == -1  # k beyond VBMP_ROWS_MAX_DIM
+    assert lib.vbmp_rows_affine_f64(null, 10, 4, some, null, 3, some, null) == -1
+    assert lib.vbmp_rows_affine_f32(null, 0, 4, null, null, 3, null, null) == 0
 
 
 def test_product_refuses_cpu_tensors(lib):

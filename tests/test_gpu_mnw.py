@@ -161,3 +161,28 @@ def test_mnw_masked_mean_primal_and_dual(keep, batch):
         assert_close(m.invV, st["invV"], 1e-10, what="invV")
         assert_close(m.invU.invU, st["W"]["invU"], 1e-10, what="invU")
         assert (m.mu[..., ~mask.to(DEV)] == 0).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("S,k,n,bias", [(100003, 6, 6, False), (70000, 7, 5, True), (1000, 1, 3, True), (513, 33, 64, False),
+                                        (300, 64, 2, True), (0, 4, 4, False)])
+def test_rows_affine(S, k, n, bias, dtype):
+    """K12 against the plain product (fp32 reference of the same op for fp32, as for every floating-point kernel)"""
+    from pyvbmp_amd import ops
+    g = torch.Generator().manual_seed(S + k)
+    X = torch.randn(S, k, generator=g, dtype=torch.float64)
+    M = torch.randn(n, k, generator=g, dtype=torch.float64)
+    c = torch.randn(n, generator=g, dtype=torch.float64) if bias else None
+    out = ops.rows_affine(X.to(dtype).to(DEV), M.to(dtype).to(DEV), None if c is None else c.to(dtype).to(DEV))
+    ref = X.to(dtype).double() @ M.to(dtype).double().T + (0 if c is None else c.to(dtype).double())
+    assert out.shape == (S, n)
+    if S:
+        assert_close(out, ref, 1e-12 if dtype == torch.float64 else 1e-5, what="rows_affine")
+
+
+def test_shared_matvec_routes_many_rows_through_k12():
+    from pyvbmp_amd._common import shared_matvec
+    g = torch.Generator().manual_seed(3)
+    G = torch.randn(5, 6, generator=g, dtype=torch.float64).to(DEV)
+    Y = torch.randn(200, 400, 6, 1, generator=g, dtype=torch.float64).to(DEV)
+    assert_close(shared_matvec(G, Y), G @ Y, 1e-12, what="shared_matvec")
