@@ -34,13 +34,19 @@ def collapse_to(t, shape):
     return t
 
 
+def _k12_pays(rows, k, n):
+    """K12 against the library GEMM, measured on MI355X (tools/exp/rows_time.py): 5-6x faster for k, n <= 9 at 1e5..4e6
+    rows in both precisions (3.9-4.7 TB/s against 0.6-0.8), even at 32 x 32 in fp64, 2.3x slower at 32 x 32 in fp32"""
+    return rows >= 16384 and k * n <= 256
+
+
 def shared_matvec(G, Y):
     """G @ Y for a stack of SHARED small matrices G (batch + (n, k), no sample axes) and per-sample vectors
     Y (sample + (1,)*len(batch) + (k, 1)): one (samples, k) x (k, batch*n) library GEMM instead of the
     samples*batch tiny matrix-vector products a broadcasting `@` is lowered to (600 000 of them, 2 ms, for the role
     emissions of the flocking DMBD).  Anything that does not have this shape goes to `@` unchanged."""
     nb = G.dim() - 2
-    if nb == 0 and Y.dim() > 2 and Y.shape[-1] == 1 and Y.is_cuda and max(G.shape) <= 64 and Y.numel() >= 65536 * G.shape[-1]:
+    if nb == 0 and Y.dim() > 2 and Y.shape[-1] == 1 and Y.is_cuda and _k12_pays(Y.numel() // G.shape[-1], G.shape[-1], G.shape[-2]):
         # ONE matrix, very many vectors (the observation messages of an LDS E-step: 4e6 rows of 6): the library GEMM for
         # such a shape runs at a tenth of the memory bandwidth; K12 streams the rows once
         from . import ops
@@ -63,3 +69,12 @@ def shared_weighted_sum(P, w):
     role-averaged likelihood precision of the flocking DMBD)."""
     R, a, b = P.shape
     return (w.reshape(-1, R) @ P.reshape(R, a * b)).reshape(tuple(w.shape[:-1]) + (a, b))
+
+
+def rows_matmul(X, W):
+    """X @ W for X = lead + (k,) with very many rows and ONE small W (k, n): K12 (one streaming pass) on the device when
+    the library GEMM would be the tall-skinny case it handles poorly (_k12_pays); `@` otherwise."""
+    if W.dim() == 2 and X.is_cuda and X.dim() >= 2 and _k12_pays(X.numel() // W.shape[0], W.shape[0], W.shape[1]):
+        from . import ops
+        return ops.rows_affine(X.reshape(-1, W.shape[0]), W.transpose(0, 1)).reshape(tuple(X.shape[:-1]) + (W.shape[1],))
+    return X @ W

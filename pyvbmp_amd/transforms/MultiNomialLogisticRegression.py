@@ -19,7 +19,7 @@ import math
 import torch
 
 from .. import ops
-from .._common import resolve
+from .._common import resolve, rows_matmul
 from ..dists.MVN_ard import MVN_ard
 from ..dists.MultivariateNormal_vector_format import MultivariateNormal_vector_format
 
@@ -30,7 +30,7 @@ def _stick_counts(Y):
     # axis costs 1.3 ms per 1e6 rows on this device, the (rows x 8) @ (8 x 8) product a few microseconds
     c = Y.shape[-1]
     tri = torch.tril(torch.ones(c, c, device=Y.device, dtype=Y.dtype))
-    N = Y @ tri
+    N = rows_matmul(Y, tri)
     return N[..., :-1], (Y - N / 2.0)[..., :-1]
 
 
@@ -174,13 +174,13 @@ class MultiNomialLogisticRegression():
         numbers are two small GEMMs against (n+1) x n constant matrices."""
         pgb_c, YmN_c = _stick_counts(torch.eye(self.n + 1, device=self.device, dtype=self.dtype))
         lc = (0.5 * pgc).cosh().log()
-        return psi @ YmN_c.transpose(0, 1) - lc @ pgb_c.transpose(0, 1) - pgb_c.sum(-1) * math.log(2.0)
+        return rows_matmul(psi, YmN_c.transpose(0, 1)) - rows_matmul(lc, pgb_c.transpose(0, 1)) - pgb_c.sum(-1) * math.log(2.0)
 
     def log_predict(self, X):
         """log-probability bound of every class: sample + batch + (n+1,) (ref :229-235)"""
         EX = self._pad(X)
         psi = (EX.unsqueeze(-2) * self.beta.mean().squeeze(-1)).sum(-1) if self.batch_dim > 0 else \
-            EX @ self.beta.mean().squeeze(-1).transpose(-2, -1)
+            rows_matmul(EX, self.beta.mean().squeeze(-1).transpose(-2, -1))
         return self._class_logits(psi, self._pgc(EX))
 
     def log_forward(self, pX):
@@ -194,7 +194,7 @@ class MultiNomialLogisticRegression():
     def log_predict_1(self, X):
         """ref :268-280"""
         X = self._pad(X)
-        lnpsb = X @ self.beta.mean().squeeze(-1).transpose(-2, -1)
+        lnpsb = rows_matmul(X, self.beta.mean().squeeze(-1).transpose(-2, -1))
         pgc = self._pgc(X)
         lnpsb_N = - (0.5 * pgc).cosh().log() - math.log(2.0)
         lnpsb_0 = -0.5 * lnpsb.sum(-1, True) + lnpsb_N.sum(-1, True)

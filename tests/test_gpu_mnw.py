@@ -186,3 +186,12 @@ def test_shared_matvec_routes_many_rows_through_k12():
     G = torch.randn(5, 6, generator=g, dtype=torch.float64).to(DEV)
     Y = torch.randn(200, 400, 6, 1, generator=g, dtype=torch.float64).to(DEV)
     assert_close(shared_matvec(G, Y), G @ Y, 1e-12, what="shared_matvec")
+
+
+def test_rows_matmul_routes_many_rows_through_k12():
+    from pyvbmp_amd._common import rows_matmul
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(300, 400, 7, generator=g, dtype=torch.float64).to(DEV)
+    W = torch.randn(7, 8, generator=g, dtype=torch.float64).to(DEV)
+    assert_close(rows_matmul(X, W.transpose(0, 1).contiguous().transpose(0, 1)), X @ W, 1e-12, what="rows_matmul")
+    assert_close(rows_matmul(X[:3], W), X[:3] @ W, 1e-12, what="rows_matmul small")

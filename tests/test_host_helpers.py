@@ -39,3 +39,11 @@ def test_shared_weighted_sum_matches_broadcast_sum():
     out = shared_weighted_sum(P, w)
     assert out.shape == (3, 2, 4, 6)
     assert torch.allclose(out, ref, rtol=1e-13, atol=1e-13)
+
+
+def test_rows_matmul_is_matmul_off_the_device():
+    from pyvbmp_amd._common import rows_matmul
+    g = torch.Generator().manual_seed(4)
+    X = torch.randn(5, 7, 3, generator=g, dtype=torch.float64)
+    W = torch.randn(3, 4, generator=g, dtype=torch.float64)
+    assert torch.equal(rows_matmul(X, W), X @ W)
