@@ -215,6 +215,15 @@ int vbmp_hmm_forward_backward_f32(const float* logits, const float* trans, const
 int vbmp_weighted_matsum_f64(const double* C, const double* w, int64_t S, int64_t E, double* out, void* stream);
 int vbmp_weighted_matsum_f32(const float* C, const float* w, int64_t S, int64_t E, float* out, void* stream);
 
+/* K5b with several weight columns: out[b,e] += sum_{s<S} W[s,b] * C[s,e], b < NB <= VBMP_MATSUM_MAX_COLS: the same
+ * covariance term when all NB experts / roles weigh the SAME per-sample matrices (a DMBD observation's latent message).
+ * C dense (S,E); W dense (S,NB); out (NB,E) MUST be zeroed by the caller (atomic accumulation). */
+#define VBMP_MATSUM_MAX_COLS 32
+int vbmp_weighted_matsum_cols_f64(const double* C, const double* W, int64_t S, int64_t E, int NB, double* out,
+                                  void* stream);
+int vbmp_weighted_matsum_cols_f32(const float* C, const float* W, int64_t S, int64_t E, int NB, float* out,
+                                  void* stream);
+
 /* K12 -- one shared small matrix applied to many rows: out[s,:] = M x[s,:] + c, s < S (the likelihood message
  * eta = E[A' R] y of every observation, MatrixNormalWishart.Elog_like_X, transforms/MatrixNormalWishart.py:251-261, on
  * the (time x series) rows of the LDS E-step).  X dense (S,k); M dense (n,k); c (n) or NULL; out dense (S,n).

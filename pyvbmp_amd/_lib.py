@@ -105,6 +105,11 @@ def _sig_matsum(T):
     return [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr]
 
 
+def _sig_matsum_cols(T):
+    # C, W, S, E, NB, out, stream
+    return [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]
+
+
 def _sig_rows(T):
     # X, S, k, M, c, n, out, stream
     return [_c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr]
@@ -124,6 +129,7 @@ SYMBOLS = {
     "vbmp_mnw_message": _sig_mnw_msg,
     "vbmp_hmm_forward_backward": _sig_hmm,
     "vbmp_weighted_matsum": _sig_matsum,
+    "vbmp_weighted_matsum_cols": _sig_matsum_cols,
     "vbmp_rows_affine": _sig_rows,
 }
 DTYPES = {"f64": (torch.float64, ctypes.c_double), "f32": (torch.float32, ctypes.c_float)}

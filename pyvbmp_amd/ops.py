@@ -479,3 +479,25 @@ def rows_affine(X, M, c=None):
         fn = getattr(lib, "vbmp_rows_affine_" + L.suffix(dt))
         L.call(fn, "vbmp_rows_affine", L.ptr(Xc), S, k, L.ptr(Mc), L.ptr(cc), n, L.ptr(out), L.stream_ptr(dev))
     return out
+
+
+MATSUM_MAX_COLS = 32
+
+
+def weighted_matsum_cols(C, W):
+    """K5b, several weight columns: out[b] = sum_s W[s, b] * C[s] for C (S, ...) dense and W (S, NB); returns
+    (NB,) + C.shape[1:] (the library GEMM W^T @ C beyond MATSUM_MAX_COLS columns)."""
+    dev = L.require_device(C, W)
+    dt = C.dtype
+    S, NB = W.shape
+    inner = tuple(C.shape[1:])
+    E = _prod(inner)
+    if NB > MATSUM_MAX_COLS or S == 0:
+        return (W.to(dt).transpose(0, 1) @ C.reshape(S, E)).reshape((NB,) + inner)
+    lib = L.load()
+    Cc = C.contiguous()
+    Wc = W.to(dt).contiguous()
+    out = torch.zeros(NB, E, dtype=dt, device=dev)
+    fn = getattr(lib, "vbmp_weighted_matsum_cols_" + L.suffix(dt))
+    L.call(fn, "vbmp_weighted_matsum_cols", L.ptr(Cc), L.ptr(Wc), S, E, NB, L.ptr(out), L.stream_ptr(dev))
+    return out.reshape((NB,) + inner)

@@ -206,7 +206,7 @@ class MatrixNormalWishart():
         """SExx, SEyx, SEyy, N (+ bias augmentation) from means / covariances / responsibilities.
         Inputs that are shared by all experts (component axes of size 1, e.g. the latent message every role of a
         DMBD observation sees) are NOT expanded over the experts: the K4 kernel reads each sample once and loops
-        over the experts, and the covariance terms become one GEMM  W^T (S x NB) @ C (S x d^2)."""
+        over the experts, and the covariance terms one streaming pass with a weight column per expert (K5b)."""
         nd = self.event_dim + self.batch_dim
         mat_batch = self.batch_shape + self.event_shape[:-2]
         nmb = len(mat_batch)
@@ -240,7 +240,7 @@ class MatrixNormalWishart():
             if shared and pw is not None and nmb > 0:
                 Cs = C.expand(sample_shape + (1,) * nmb + (d, d)).reshape(S, d * d)
                 W = pw.expand(full).reshape(S, -1)
-                return (W.transpose(0, 1) @ Cs).reshape(mat_batch + (d, d))
+                return ops.weighted_matsum_cols(Cs, W).reshape(mat_batch + (d, d))
             C = C.expand(full + (d, d))
             if pw is None:
                 return C.sum(tuple(range(nsd)))

@@ -195,3 +195,18 @@ def test_rows_matmul_routes_many_rows_through_k12():
     W = torch.randn(7, 8, generator=g, dtype=torch.float64).to(DEV)
     assert_close(rows_matmul(X, W.transpose(0, 1).contiguous().transpose(0, 1)), X @ W, 1e-12, what="rows_matmul")
     assert_close(rows_matmul(X[:3], W), X[:3] @ W, 1e-12, what="rows_matmul small")
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("S,inner,NB", [(24000, (53, 53), 25), (25600, (7, 7), 4), (5000, (8, 8), 1), (70, (4, 4), 32), (333, (3,), 5),
+                                        (100, (6, 6), 33)])
+def test_weighted_matsum_cols(S, inner, NB, dtype):
+    """K5b with a weight column per expert against W^T @ C (odd and even matrix sizes, up to and beyond the column limit)"""
+    from pyvbmp_amd import ops
+    g = torch.Generator().manual_seed(S + NB)
+    C = torch.randn((S,) + inner, generator=g, dtype=torch.float64)
+    W = torch.rand(S, NB, generator=g, dtype=torch.float64)
+    out = ops.weighted_matsum_cols(C.to(dtype).to(DEV), W.to(dtype).to(DEV))
+    ref = (W.to(dtype).double().T @ C.to(dtype).double().reshape(S, -1)).reshape((NB,) + inner)
+    assert out.shape == (NB,) + inner
+    assert_close(out, ref, 1e-12 if dtype == torch.float64 else 2e-5, what="matsum_cols")

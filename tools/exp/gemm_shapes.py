@@ -8,7 +8,13 @@ from pyvbmp_amd.models import DynamicMarkovBlanketDiscovery, LinearDynamicalSyst
 
 what = sys.argv[1] if len(sys.argv) > 1 else "dmbd"
 g = torch.Generator(device="cuda").manual_seed(0)
-if what == "dmbd":
+if what == "dmbd6":
+    T, S, n_obs = 400, 64, 1
+    y = torch.randn(T, S, n_obs, 6, generator=g, device="cuda", dtype=torch.float64).cumsum(0) * 0.05
+    m = DynamicMarkovBlanketDiscovery(obs_shape=(n_obs, 6), role_dims=(1, 2, 1), hidden_dims=(2, 2, 2), number_of_objects=1,
+                                      device="cuda", dtype=torch.float64)
+    run = lambda: m.update(y, None, None, iters=1, lr=0.5)
+elif what == "dmbd":
     T, S, n_obs = 100, 20, 12
     y = boids(T, S, n_obs, g)
     m = DynamicMarkovBlanketDiscovery(obs_shape=(n_obs, 4), role_dims=(1, 2, 2), hidden_dims=(4, 4, 4), number_of_objects=6,
