@@ -158,7 +158,9 @@ int vbmp_lds_smoother_f32(const vbmp_lds_args_f32* args, void* stream);
  * models/LinearDynamicalSystems.py:173-190):  out[s,i,j] = sum_{t<Tn} a[t,s,i]*b[t,s,j] (+ sum_t M[t,s,i,j]).
  * a: element (t,s,i) at a + t*sa_t + s*sa_s + i (strides in elements, 0 = constant along that axis); b alike
  * with db entries; M (nullable): (t,s,i,j) at M + t*sM_t + s*sM_s + i*db + j.  out dense (S,da,db).
- * Time-shifted operands (mu[:-1] against mu[1:]) are expressed by offsetting the base pointers. */
+ * Time-shifted operands (mu[:-1] against mu[1:]) are expressed by offsetting the base pointers.
+ * With few outputs and many steps the time axis is cut into chunks that are combined with atomics (the last bits of
+ * out then depend on arrival order). */
 int vbmp_tsum_outer_f64(const double* a, int64_t sa_t, int64_t sa_s, int da, const double* b, int64_t sb_t, int64_t sb_s,
                         int db, const double* M, int64_t sM_t, int64_t sM_s, int64_t Tn, int64_t S, double* out,
                         void* stream);
