@@ -233,9 +233,16 @@ template <> struct MomMfma<float, 32> {
 };
 
 template <typename T, int TILE, int NT, int BO>  // NT feature tiles of TILE, BO <= 4 components per pass
-__global__ __launch_bounds__(256) void k_wmom_mfma(const T* __restrict__ X, const T* __restrict__ p, int64_t S, int D,
-                                                    int ps, T* __restrict__ Nk, T* __restrict__ SEx,
-                                                    T* __restrict__ SExx) {
+__global__ __launch_bounds__(256) void k_wmom_mfma(const T* __restrict__ X, const T* __restrict__ p_all, int64_t S, int D,
+                                                    int ps, T* __restrict__ Nk_all, T* __restrict__ SEx_all,
+                                                    T* __restrict__ SExx_all) {
+  // blockIdx.y = group of BO components: the passes over X for the groups of a wide statistic run side by side
+  // instead of as one launch after the other (25 roles of a 57-wide moment: 25 launches of 24 blocks each)
+  const int64_t k0 = (int64_t)blockIdx.y * BO;
+  const T* __restrict__ p = p_all ? p_all + k0 : p_all;
+  T* __restrict__ Nk = Nk_all + k0;
+  T* __restrict__ SEx = SEx_all + k0 * D;
+  T* __restrict__ SExx = SExx_all + k0 * D * D;
   using M = MomMfma<T, TILE>;
   using acc_t = typename M::acc_t;
   constexpr int SPS = 64 / TILE, U = 4;
@@ -359,16 +366,26 @@ static int wmom_mfma(const T* X, const T* p, int64_t S, int64_t Bo, int D, T* Nk
   const int64_t cap = g_vbmp_blocks_per_cu > 0 ? 256 * (int64_t)g_vbmp_blocks_per_cu : 1024;  // debug override
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
-  const dim3 g((unsigned)blocks), b(256);
-#define VBMP_WM(NT, BO)                                                                                          \
-  hipLaunchKernelGGL((k_wmom_mfma<T, TILE, NT, BO>), g, b, 0, st, X, p ? p + k0 : p, S, D, (int)Bo, Nk + k0,        \
-                     SEx + k0 * D, SExx + k0 * D * D)
+  const dim3 b(256);
+#define VBMP_WM(NT, BO)                                                                                              \
+  hipLaunchKernelGGL((k_wmom_mfma<T, TILE, NT, BO>), dim3((unsigned)blocks, (unsigned)ngroups), b, 0, st, X,          \
+                     p ? p + k0 : p, S, D, (int)Bo, Nk + k0, SEx + k0 * D, SExx + k0 * D * D)
   const int nt = (D + TILE - 1) / TILE;
   // components in groups per pass over X (accumulators live in registers: BO * NT^2 tiles, so wide statistics take
-  // fewer components per pass: 4 for NT <= 2, 2 for NT = 3, 1 for NT = 4)
+  // fewer components per pass: 4 for NT <= 2, 2 for NT = 3, 1 for NT = 4); all full groups go out as ONE launch
+  // (grid.y), a last partial group as a second one
   const int64_t group = nt <= 2 ? 4 : (nt == 3 ? 2 : 1);
-  for (int64_t k0 = 0; k0 < Bo; k0 += group) {
-    const int64_t nb = Bo - k0 < group ? Bo - k0 : group;
+  const int64_t full = Bo / group, rem = Bo - full * group;
+  bool tail_done = (rem == 0);
+  for (int64_t done = 0; done < full || !tail_done;) {
+    const bool tail = done == full;  // the partial group, after all full ones (grid.y holds at most 65535 of those)
+    const int64_t k0 = done * group;
+    const int64_t nb = tail ? rem : group;
+    const int64_t ngroups = tail ? 1 : (full - done < 65535 ? full - done : 65535);
+    if (tail)
+      tail_done = true;
+    else
+      done += ngroups;
     if (nt == 1) {
       if (nb == 1) VBMP_WM(1, 1); else if (nb == 2) VBMP_WM(1, 2); else if (nb == 3) VBMP_WM(1, 3); else VBMP_WM(1, 4);
     } else if (nt == 2) {
