@@ -189,3 +189,25 @@ def test_mixture_of_linear_transforms_golden(golden, case):
     assert_close(m.ELBO_last, c["upd_ELBO"], 1e-9, what="upd ELBO")
     assert_close(m.W.mu, c["upd_W_mu"], 1e-9, what="upd W_mu")
     assert_close(m.pi.alpha, c["upd_pi_alpha"], 1e-9, what="upd alpha")
+
+
+@pytest.mark.parametrize("keep,batch", [(0.25, ()), (0.75, (3,))])
+def test_mng_masked_mean_rowwise_equals_the_dense_systems(keep, batch):
+    """diagonal noise: the row-separable constrained mean (one batched K1 launch) against the dense primal / dual
+    systems of the parent class on the same posterior"""
+    import torch
+    from pyvbmp_amd.transforms import MatrixNormalGamma, MatrixNormalWishart
+    n, p = 9, 11
+    g = torch.Generator().manual_seed(int(100 * keep))
+    mask = torch.rand(n, p, generator=g) < keep
+    mask[torch.arange(n), torch.arange(n)] = True
+    m = MatrixNormalGamma((n, p), batch, mask=mask.to(DEV), device=DEV, dtype=torch.float64)
+    m.invU.gamma.alpha = m.invU.gamma.alpha * (1.0 + torch.rand(m.invU.gamma.alpha.shape, generator=g, dtype=torch.float64).to(DEV))
+    A = torch.randn(batch + (p, p + 3), generator=g, dtype=torch.float64).to(DEV)
+    invV = A @ A.transpose(-2, -1) + torch.eye(p, dtype=torch.float64, device=DEV)
+    mu = torch.randn(batch + (n, p), generator=g, dtype=torch.float64).to(DEV)
+    V = torch.linalg.inv(invV)
+    got = m._constrain_mean(mu, invV, V)
+    ref = MatrixNormalWishart._constrain_mean(m, mu, invV, V)
+    assert_close(got, ref, 1e-11, what="constrained mean")
+    assert (got[..., ~mask.to(DEV)] == 0).all()
