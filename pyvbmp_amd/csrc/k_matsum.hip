@@ -66,38 +66,54 @@ __global__ __launch_bounds__(256) void k_weighted_matsum_cols(const T* __restric
   const int64_t s0 = (int64_t)blockIdx.y * chunk;
   const int64_t s1 = (s0 + chunk < S) ? s0 + chunk : S;
   const int64_t ev = E / V;
-  for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < ev; c += (int64_t)gridDim.x * 256) {
+  // the weights of SUB samples at a time sit in LDS, rows padded to NBP with zeros: every lane reads the same words (a
+  // broadcast) and the inner loop needs no `b < NB` guard.  (Read straight from global memory they are NB scalar loads
+  // per sample and wave, which bound the first version of this kernel at 1.2 TB/s.)
+  constexpr int SUB = 64;
+  __shared__ __attribute__((aligned(16))) T wsm[SUB * NBP];
+  for (int e = threadIdx.x; e < SUB * NBP; e += 256) wsm[e] = T(0);
+  for (int64_t cg = blockIdx.x; cg * 256 < ev; cg += gridDim.x) {  // block-uniform: the barriers below are reached by all
+    const int64_t c = cg * 256 + threadIdx.x;
+    const bool active = c < ev;
     vec_t acc[NBP];
 #pragma unroll
     for (int b = 0; b < NBP; ++b) acc[b] = vec_t{};
-    const vec_t* base = reinterpret_cast<const vec_t*>(C) + c;
-    constexpr int U = 4;
-    int64_t s = s0;
-    for (; s + U <= s1; s += U) {
-      vec_t v[U];
+    const vec_t* base = reinterpret_cast<const vec_t*>(C) + (active ? c : 0);
+    for (int64_t sb = s0; sb < s1; sb += SUB) {
+      const int n = (int)((s1 - sb) < SUB ? (s1 - sb) : SUB);
+      __syncthreads();  // the previous sub-chunk's readers are done
+      for (int e = threadIdx.x; e < n * NB; e += 256) {
+        const int i = e / NB;
+        wsm[i * NBP + (e - i * NB)] = W[sb * NB + e];
+      }
+      __syncthreads();
+      if (active) {
+        constexpr int U = 4;
+        int i = 0;
+        for (; i + U <= n; i += U) {
+          vec_t v[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(&base[(s + u) * ev]);
+          for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(&base[(sb + i + u) * ev]);
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const T* w = W + (s + u) * NB;
+          for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int b = 0; b < NBP; ++b)
-          if (b < NB) acc[b] += w[b] * v[u];
+            for (int b = 0; b < NBP; ++b) acc[b] += wsm[(i + u) * NBP + b] * v[u];
+        }
+        for (; i < n; ++i) {
+          const vec_t v = base[(sb + i) * ev];
+#pragma unroll
+          for (int b = 0; b < NBP; ++b) acc[b] += wsm[i * NBP + b] * v;
+        }
       }
     }
-    for (; s < s1; ++s) {
-      const vec_t v = base[s * ev];
-      const T* w = W + s * NB;
+    if (active) {
 #pragma unroll
-      for (int b = 0; b < NBP; ++b)
-        if (b < NB) acc[b] += w[b] * v;
-    }
+      for (int b = 0; b < NBP; ++b) {
+        if (b < NB) {
+          const vec_t a = acc[b];
 #pragma unroll
-    for (int b = 0; b < NBP; ++b) {
-      if (b < NB) {
-        const vec_t a = acc[b];
-#pragma unroll
-        for (int u = 0; u < V; ++u) atomicAdd(&out[(int64_t)b * E + c * V + u], a[u]);
+          for (int u = 0; u < V; ++u) atomicAdd(&out[(int64_t)b * E + c * V + u], a[u]);
+        }
       }
     }
   }
