@@ -132,7 +132,9 @@ class MultiNomialLogisticRegression():
         YmNw = YmN if w is None else YmN * w
         flat = self.batch_dim == 0
         if flat:
-            SEyx = (YmNw.reshape(-1, self.n).transpose(0, 1) @ EX.reshape(-1, self.p)).unsqueeze(-1)
+            # one weight column per logit, the sample axis reduced by K5b (as a library GEMM it is the inner dimension:
+            # tens of milliseconds in fp64 at 1e5..1e6 samples)
+            SEyx = ops.weighted_matsum_cols(EX.reshape(-1, self.p), YmNw.reshape(-1, self.n)).unsqueeze(-1)
         else:
             SEyx = (YmNw.reshape(tuple(YmNw.shape) + (1, 1)) * EX.unsqueeze(-3)).sum(sample_dims)
         for i in range(iters):
@@ -140,7 +142,7 @@ class MultiNomialLogisticRegression():
             Ew = _ew(pgb, pgc)
             Eww = Ew if w is None else Ew * w
             if flat:
-                SExx = (Eww.reshape(-1, self.n).transpose(0, 1) @ EXXT.reshape(-1, self.p * self.p)).reshape(self.n, self.p, self.p)
+                SExx = ops.weighted_matsum_cols(EXXT.reshape(-1, self.p, self.p), Eww.reshape(-1, self.n))
             else:
                 SExx = (Eww.reshape(tuple(Eww.shape) + (1, 1)) * EXXT.unsqueeze(-3)).sum(sample_dims)
             if verbose is True:
