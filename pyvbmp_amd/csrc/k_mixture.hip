@@ -606,57 +606,55 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_estep_softmax(T* __restrict__ p, int64_t S, int K, T* __restrict__ NA,
                                                        T* __restrict__ logZ) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* sNA = reinterpret_cast<T*>(smem_raw);  // K + 1
-  T* sL = sNA + (K + 1);                    // 256 x (K + 1)
   const int KS = K + 1;
-  for (int k = threadIdx.x; k <= K; k += 256) sNA[k] = T(0);
-  const int lane = threadIdx.x & 63;
+  T* sL = reinterpret_cast<T*>(smem_raw);  // 256 x (K + 1): the rows of the current chunk (odd-ish stride)
+  T* sAcc = sL + 256 * KS;                 // 256 x (K + 1): per-thread running sums of p[s, k] (slot K: log-sum-exp)
+  T* acc = sAcc + threadIdx.x * KS;
+  for (int k = 0; k <= K; ++k) acc[k] = T(0);
+  // e / K for e < 256 K <= 2^16 as a multiply-high (exact for these ranges): the re-layout loops below run it per element
+  const unsigned int kinv = 0xFFFFFFFFu / (unsigned int)K + 1u;
   for (int64_t s0 = (int64_t)blockIdx.x * 256; s0 < S; s0 += (int64_t)gridDim.x * 256) {
     const int64_t n = ((S - s0) < 256 ? (S - s0) : 256) * K;
     T* src = p + s0 * K;
     __syncthreads();
     for (int e = threadIdx.x; e < n; e += 256) {
-      const int r = e / K, k = e - r * K;
+      const int r = (int)__umulhi((unsigned int)e, kinv), k = e - r * K;
       sL[r * KS + k] = src[e];
     }
     __syncthreads();
-    const bool live = s0 + threadIdx.x < S;
-    T* row = sL + threadIdx.x * KS;
-    T mx = -INFINITY;
-    if (live)
+    if (s0 + threadIdx.x < S) {
+      T* row = sL + threadIdx.x * KS;
+      T mx = -INFINITY;
       for (int k = 0; k < K; ++k) mx = row[k] > mx ? row[k] : mx;
-    T sum = T(0);
-    if (live)
+      T sum = T(0);
       for (int k = 0; k < K; ++k) {
         const T e = exp(row[k] - mx);  // one exp per entry; normalised by a multiply below
         row[k] = e;
         sum += e;
       }
-    const T lse = live ? mx + log(sum) : T(0);
-    const T inv = live ? T(1) / sum : T(0);
-    for (int k = 0; k < K; ++k) {
-      T v = T(0);
-      if (live) {
-        v = row[k] * inv;
+      const T inv = T(1) / sum;
+      for (int k = 0; k < K; ++k) {
+        const T v = row[k] * inv;
         row[k] = v;
+        acc[k] += v;  // own slot: no exchange per chunk, one block-level sum at the very end
       }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-      if (lane == 0) atomicAdd(&sNA[k], v);
+      acc[K] += mx + log(sum);
     }
-    T z = lse;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off, 64);
-    if (lane == 0) atomicAdd(&sNA[K], z);
     __syncthreads();
     for (int e = threadIdx.x; e < n; e += 256) {
-      const int r = e / K, k = e - r * K;
+      const int r = (int)__umulhi((unsigned int)e, kinv), k = e - r * K;
       src[e] = sL[r * KS + k];
     }
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < K; k += 256) atomicAdd(&NA[k], sNA[k]);
-  if (threadIdx.x == 0) atomicAdd(logZ, sNA[K]);
+  for (int k = threadIdx.x; k <= K; k += 256) {
+    T tot = T(0);
+    for (int r = 0; r < 256; ++r) tot += sAcc[r * KS + k];
+    if (k < K)
+      atomicAdd(&NA[k], tot);
+    else
+      atomicAdd(logZ, tot);
+  }
 }
 
 // launch of the MFMA quadratic form; returns false when the shape is not served (caller falls back to k_quadform)
@@ -717,14 +715,17 @@ static int estep_dispatch(const T* X, int64_t S, int K, int D, const T* P, const
   int64_t blocks = (S + 255) / 256;
   if (blocks > 256 * 8) blocks = 256 * 8;
   // D >= 8: log-likelihoods on the matrix cores into the p buffer, then the in-place softmax pass
-  if (!(g_vbmp_flags & 0x100) && (size_t)257 * (K + 1) * sizeof(T) <= 60 * 1024 &&
-      quadform_mfma_launch<T>(X, S, K, 1, D, P, b, c, p, st)) {
-    hipLaunchKernelGGL((k_estep_softmax<T>), dim3((unsigned)blocks), dim3(256), (size_t)257 * (K + 1) * sizeof(T), st, p,
-                       S, K, NA, logZ);
+  const size_t sm_smem = (size_t)512 * (K + 1) * sizeof(T);  // rows of a chunk + per-thread running sums
+  if (!(g_vbmp_flags & 0x100) && sm_smem <= 150 * 1024 && quadform_mfma_launch<T>(X, S, K, 1, D, P, b, c, p, st)) {
+    if (sm_smem > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_estep_softmax<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sm_smem) != hipSuccess)
+      return VBMP_ERR_LAUNCH;
+    hipLaunchKernelGGL((k_estep_softmax<T>), dim3((unsigned)blocks), dim3(256), sm_smem, st, p, S, K, NA, logZ);
     return hipGetLastError() == hipSuccess ? 0 : VBMP_ERR_LAUNCH;
   }
   size_t smem = (size_t)(K + 1) * sizeof(T);
-  const size_t staged = (size_t)257 * (K + 1) * sizeof(T);
+  const size_t staged = (size_t)512 * (K + 1) * sizeof(T);
   const int stage = staged <= 40 * 1024;
   if (stage) smem = staged;
   VBMP_DISPATCH_DIM(T, D, {
