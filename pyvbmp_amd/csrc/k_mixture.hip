@@ -89,6 +89,9 @@ __global__ __launch_bounds__(256) void k_mixture_estep(const T* __restrict__ X, 
   T* sL = sNA + (K + 1);
   const int KS = K + 1;
   for (int k = threadIdx.x; k <= K; k += 256) sNA[k] = T(0);
+  if (stage)
+    for (int k = 0; k <= K; ++k) sL[256 * KS + threadIdx.x * KS + k] = T(0);  // this thread's running sums
+  const unsigned int kinv = 0xFFFFFFFFu / (unsigned int)K + 1u;
   __syncthreads();
   const int lane = threadIdx.x & 63;
   // grid-stride over samples: the same-address global atomics at the end are per block, so the grid is capped
@@ -116,41 +119,59 @@ __global__ __launch_bounds__(256) void k_mixture_estep(const T* __restrict__ X, 
       lse = mx + log(sum);
       inv = T(1) / sum;
     }
-    // last pass: normalise in place and reduce the responsibilities over the wave, then the block
-    for (int k = 0; k < K; ++k) {
-      T v = T(0);
-      if (live) {
-        if (stage) {
-          v = sL[threadIdx.x * KS + k] * inv;
-          sL[threadIdx.x * KS + k] = v;
-        } else {
-          v = lrow[k] * inv;
-          lrow[k] = v;
-        }
-      }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-      if (lane == 0) atomicAdd(&sNA[k], v);
-    }
-    T z = live ? lse : T(0);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off, 64);
-    if (lane == 0) atomicAdd(&sNA[K], z);
+    // last pass: normalise in place and sum the responsibilities
     if (stage) {
+      // staged form: every thread keeps running sums in its own LDS slots (one block-level reduction at the very end
+      // instead of K + 1 wave butterflies per 256 samples)
+      T* acc = sL + 256 * KS + threadIdx.x * KS;
+      if (live) {
+        for (int k = 0; k < K; ++k) {
+          const T v = sL[threadIdx.x * KS + k] * inv;
+          sL[threadIdx.x * KS + k] = v;
+          acc[k] += v;
+        }
+        acc[K] += lse;
+      }
       __syncthreads();
       const int64_t s0 = s - threadIdx.x;
       const int64_t n = ((S - s0) < 256 ? (S - s0) : 256) * K;
       T* dst = p + s0 * K;
       for (int e = threadIdx.x; e < n; e += 256) {
-        const int r = e / K, k = e - r * K;
+        const int r = (int)__umulhi((unsigned int)e, kinv), k = e - r * K;  // e / K, exact for e < 2^16
         dst[e] = sL[r * KS + k];
       }
       __syncthreads();
+    } else {
+      for (int k = 0; k < K; ++k) {
+        T v = T(0);
+        if (live) {
+          v = lrow[k] * inv;
+          lrow[k] = v;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) atomicAdd(&sNA[k], v);
+      }
+      T z = live ? lse : T(0);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off, 64);
+      if (lane == 0) atomicAdd(&sNA[K], z);
     }
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < K; k += 256) atomicAdd(&NA[k], sNA[k]);
-  if (threadIdx.x == 0) atomicAdd(logZ, sNA[K]);
+  if (stage) {
+    for (int k = threadIdx.x; k <= K; k += 256) {
+      T tot = T(0);
+      for (int r = 0; r < 256; ++r) tot += sL[256 * KS + r * KS + k];
+      if (k < K)
+        atomicAdd(&NA[k], tot);
+      else
+        atomicAdd(logZ, tot);
+    }
+  } else {
+    for (int k = threadIdx.x; k < K; k += 256) atomicAdd(&NA[k], sNA[k]);
+    if (threadIdx.x == 0) atomicAdd(logZ, sNA[K]);
+  }
 }
 
 // ------------------------------------------------------------------------------------ K4
@@ -725,7 +746,7 @@ static int estep_dispatch(const T* X, int64_t S, int K, int D, const T* P, const
     return hipGetLastError() == hipSuccess ? 0 : VBMP_ERR_LAUNCH;
   }
   size_t smem = (size_t)(K + 1) * sizeof(T);
-  const size_t staged = (size_t)512 * (K + 1) * sizeof(T);
+  const size_t staged = (size_t)513 * (K + 1) * sizeof(T);  // block partials | 256 rows of a chunk | 256 rows of running sums
   const int stage = staged <= 40 * 1024;
   if (stage) smem = staged;
   VBMP_DISPATCH_DIM(T, D, {
