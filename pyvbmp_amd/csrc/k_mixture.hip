@@ -9,6 +9,13 @@ extern "C" int g_vbmp_blocks_per_cu;
 
 namespace vbmp {
 
+// e / K by multiply-high with kinv = floor((2^32 - 1) / K) + 1: exact for e < 2^16 and 2 <= K; for K == 1 the
+// reciprocal does not fit 32 bits (kinv wraps to 0), so that case is the identity
+__device__ __forceinline__ int div_small(int e, unsigned int kinv, int K) {
+  return K == 1 ? e : (int)__umulhi((unsigned int)e, kinv);
+}
+
+
 // one sample row in registers (zero padded to Dp)
 template <typename T, int Dp>
 __device__ __forceinline__ void load_row(const T* __restrict__ x, int D, T (&r)[Dp]) {
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(256) void k_mixture_estep(const T* __restrict__ X, 
       const int64_t n = ((S - s0) < 256 ? (S - s0) : 256) * K;
       T* dst = p + s0 * K;
       for (int e = threadIdx.x; e < n; e += 256) {
-        const int r = (int)__umulhi((unsigned int)e, kinv), k = e - r * K;  // e / K, exact for e < 2^16
+        const int r = div_small(e, kinv, K), k = e - r * K;  // e / K, exact for e < 2^16
         dst[e] = sL[r * KS + k];
       }
       __syncthreads();
@@ -639,7 +646,7 @@ __global__ __launch_bounds__(256) void k_estep_softmax(T* __restrict__ p, int64_
     T* src = p + s0 * K;
     __syncthreads();
     for (int e = threadIdx.x; e < n; e += 256) {
-      const int r = (int)__umulhi((unsigned int)e, kinv), k = e - r * K;
+      const int r = div_small(e, kinv, K), k = e - r * K;
       sL[r * KS + k] = src[e];
     }
     __syncthreads();
@@ -663,7 +670,7 @@ __global__ __launch_bounds__(256) void k_estep_softmax(T* __restrict__ p, int64_
     }
     __syncthreads();
     for (int e = threadIdx.x; e < n; e += 256) {
-      const int r = (int)__umulhi((unsigned int)e, kinv), k = e - r * K;
+      const int r = div_small(e, kinv, K), k = e - r * K;
       src[e] = sL[r * KS + k];
     }
   }

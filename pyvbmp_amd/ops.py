@@ -193,9 +193,10 @@ def mixture_estep(X, P, b, c):
     S = Xc.shape[0]
     p = torch.empty((S, K), dtype=dt, device=dev)
     acc = torch.zeros(K + 1, dtype=dt, device=dev)
+    Pc, bc, cc = P.contiguous(), b.contiguous(), c.contiguous()  # named: a temporary's block could be reused before the launch
     if S > 0:
         fn = getattr(lib, "vbmp_mixture_estep_" + L.suffix(dt))
-        L.call(fn, "vbmp_mixture_estep", L.ptr(Xc), S, K, D, L.ptr(P.contiguous()), L.ptr(b.contiguous()), L.ptr(c.contiguous()), L.ptr(p),
+        L.call(fn, "vbmp_mixture_estep", L.ptr(Xc), S, K, D, L.ptr(Pc), L.ptr(bc), L.ptr(cc), L.ptr(p),
                    L.ptr(acc), ctypes.c_void_p(acc.data_ptr() + K * acc.element_size()), L.stream_ptr(dev))
     return p, acc[:K], acc[K]
 

@@ -62,6 +62,51 @@ def test_dmbd_golden(golden, case):
     assert_close(m.particular_assignment_pr(), c["particular_assignment_pr"], 1e-6)
 
 
+def test_dmbd_flocking_hyperparameters_golden(golden):
+    """BASELINE configs[4] at the reference example's exact hyper-parameters (examples/Flocking_example.py:38:
+    role_dims=(1,2,2), hidden_dims=(4,4,4), number_of_objects=6, regression_dim=-1 -> hidden 52, 25 roles) against two VB
+    iterations of the imported reference on boids data (T=20, 2 runs, 12 birds).  This drives the block-per-series
+    smoother (h = 52), the K = 25 masked role chain, the masked transition / emission updates."""
+    from pyvbmp_amd.models import DynamicMarkovBlanketDiscovery
+    c = golden("dmbd_flock")["dmbd_flocking"]
+    m = DynamicMarkovBlanketDiscovery(obs_shape=(12, 4), role_dims=(1, 2, 2), hidden_dims=(4, 4, 4), regression_dim=-1,
+                                      control_dim=0, number_of_objects=6, unique_obs=False, device=DEV, dtype=torch.float64)
+    assert m.hidden_dim == 52 and m.obs_model.transition_mask.shape == (25, 25)
+    assert torch.equal(m.A.mask.cpu(), c["A_mask"])
+    assert torch.equal(m.B.X_mask.cpu(), c["B_X_mask"])
+    assert torch.equal(m.obs_model.transition_mask.cpu(), c["role_mask"])
+    assert_close(m.B.invU.invU_0, c["init_B_invU_0"])
+    m.x0.mu = c["init_x0_mu"].to(DEV)
+    m.A.mu = c["init_A_mu"].to(DEV)
+    m.A.invU.gamma.alpha = c["init_A_alpha"].to(DEV)
+    m.A.invU.gamma.beta = c["init_A_beta"].to(DEV)
+    m.B.mu = c["init_B_mu"].to(DEV)
+    m.obs_model.transition.alpha = c["init_trans_alpha"].to(DEV)
+    m.obs_model.initial.alpha = c["init_init_alpha"].to(DEV)
+    m.set_latent_parms()
+    y = c["y"].to(DEV)
+    for it in (1, 2):
+        pre = f"it{it}_"
+        tol = 1e-8 if it == 1 else 1e-6  # the second iteration starts from the first one's rounding differences
+        m.update(y, None, None, iters=1, latent_iters=1, lr=1.0)
+        assert_close(m.obs_model.p, c[pre + "p"], tol, what=pre + "p")
+        assert_close(m.NA, c[pre + "NA"], tol, what=pre + "NA")
+        assert_close(m.SEzz, c[pre + "SEzz"], tol, what=pre + "SEzz")
+        assert_close(m.SEz0, c[pre + "SEz0"], tol, what=pre + "SEz0")
+        assert_close(m.logZ, c[pre + "logZ"], tol, what=pre + "logZ")
+        assert_close(m.ELBO_last, c[pre + "ELBO"], tol, what=pre + "ELBO")
+        assert_close(m.px.mu, c[pre + "px_mu"], tol, what=pre + "px mu")
+        assert_close(m.A.mu, c[pre + "A_mu"], tol, what=pre + "A mu")
+        assert_close(m.A.invU.gamma.beta, c[pre + "A_beta"], tol, what=pre + "A beta")
+        if float(c[pre + "B_mu"].abs().max()) == 0.0:
+            assert float(m.B.mu.abs().max()) == 0.0
+        else:
+            assert_close(m.B.mu, c[pre + "B_mu"], tol, what=pre + "B mu")
+        assert_close(m.B.invU.invU, c[pre + "B_invU_invU"], tol, what=pre + "B invU")
+        assert_close(m.x0.mu, c[pre + "x0_mu"], tol, what=pre + "x0 mu")
+        assert_close(m.obs_model.transition.alpha, c[pre + "trans_alpha"], tol, what=pre + "trans alpha")
+
+
 class _PairReducer:
     """two 'ranks' (threads on one GPU) with a barrier standing in for the all-reduce"""
 

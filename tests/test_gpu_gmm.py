@@ -241,7 +241,8 @@ def test_quadform_mfma_and_valu_forms(S, Bo, Bi, D, dtype, smoother_flags):
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
-@pytest.mark.parametrize("S,K,D", [(4099, 4, 16), (2500, 33, 12), (3001, 6, 40), (2048, 2, 64)])
+@pytest.mark.parametrize("S,K,D", [(4099, 4, 16), (2500, 33, 12), (3001, 6, 40), (2048, 2, 64),
+                                   (3000, 1, 4), (4099, 1, 16), (2049, 1, 2), (5000, 2, 4)])  # K = 1: single-component mixture
 def test_mixture_estep_mfma_and_valu_forms(S, K, D, dtype, smoother_flags):
     from pyvbmp_amd import ops
     g = torch.Generator().manual_seed(S + K)

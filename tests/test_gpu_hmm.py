@@ -1,5 +1,5 @@
-"""GPU parity of the K11 HMM forward-backward kernel against a plain log-space restatement (the algorithm of the
-reference's models/HMM.py:72-105, written here with torch CPU ops) on seeded inputs incl. forbidden transitions."""
+"""GPU parity of the K11 HMM forward-backward kernel against outputs of the reference (tests/golden/hmm.npz) and, on larger
+seeded inputs incl. forbidden transitions and extreme logits, against the CPU oracle (oracle/hmm.py)."""
 import pytest
 import torch
 
@@ -10,34 +10,53 @@ DEV = "cuda"
 
 
 def hmm_reference(logits, trans, init, ptemp):
-    lse = torch.logsumexp
-    T = logits.shape[0]
-    fw = [None] * T
-    fw[0] = lse(init.unsqueeze(-1) + trans + logits[0].unsqueeze(-2), -2)
-    for t in range(1, T):
-        fw[t] = lse(fw[t - 1].unsqueeze(-1) + trans + logits[t].unsqueeze(-2), -2)
-    logZ = lse(fw[-1], -1, True)
-    fw = [f - logZ for f in fw]
-    SEzz = torch.zeros(fw[0].shape + fw[0].shape[-1:], dtype=logits.dtype)
-    for t in range(T - 2, -1, -1):
-        temp = fw[t].unsqueeze(-1) + trans
-        xi = (temp - lse(temp, -2, True)) + fw[t + 1].unsqueeze(-2)
-        fw[t] = lse(xi, -1)
-        SEzz = SEzz + (xi - lse(xi, (-1, -2), True)).exp()
-    temp = init.unsqueeze(-1) + trans
-    xi = (temp - lse(temp, -2, True)) + fw[0].unsqueeze(-2)
-    z0 = lse(xi, -1)
-    SEz0 = (z0 - lse(z0, -1, True)).exp()
-    SEzz = SEzz + (xi - lse(xi, (-1, -2), True)).exp()
-    p = torch.stack(fw)
-    p = ((p - p.max(-1, keepdim=True)[0]) / ptemp).exp()
-    return p / p.sum(-1, keepdim=True), SEzz, SEz0, logZ.squeeze(-1)
+    """the CPU oracle (oracle/hmm.py, pinned to the reference's models/HMM.py:72-105 by tests/golden/hmm.npz)"""
+    from oracle import hmm as ohmm
+    return ohmm.forward_backward(logits, trans, init, ptemp)
+
+
+HMM_CASES = ["hmm_k25_roles", "hmm_k25_roles_ptemp", "hmm_k4", "hmm_k3_b2", "hmm_k9_T1", "hmm_k2_T2"]
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("case", HMM_CASES)
+def test_hmm_forward_backward_golden(golden, case, dtype):
+    """K11 against outputs of the reference's HMM.forward_backward_logits (K = 25 with the masked role transitions of the
+    flocking DMBD, ptemp != 1, batched transition matrices, T = 1 and T = 2)"""
+    from pyvbmp_amd import ops
+    c = golden("hmm")[case]
+    batch = tuple(int(v) for v in c["batch_shape"])
+    p, SEzz, SEz0, logZ = ops.hmm_forward_backward(c["logits"].to(DEV, dtype), c["trans"].to(DEV, dtype), c["init"].to(DEV, dtype),
+                                                   batch, float(c["ptemp"]))
+    tol = 1e-10 if dtype == torch.float64 else TOL32
+    assert_close(p, c["p"], tol, what="p")
+    assert_close(SEzz, c["SEzz"], tol, what="SEzz")
+    assert_close(SEz0, c["SEz0"], tol, what="SEz0")
+    assert_close(logZ, c["logZ"], tol, what="logZ")
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_hmm_class_golden(golden, dtype):
+    """the product's HMM class (its Dirichlet nodes feed K11) on the K = 25 role-chain golden"""
+    from pyvbmp_amd.dists import NormalInverseWishart
+    from pyvbmp_amd.models.HMM import HMM
+    c = golden("hmm")["hmm_k25_roles"]
+    K = int(c["K"])
+    h = HMM(NormalInverseWishart((2,), (K,), device=DEV, dtype=dtype), transition_mask=c["mask"].to(DEV), ptemp=float(c["ptemp"]))
+    # loggeomean is what the kernel consumes: check the class against it at its own Dirichlet state, then replay
+    h.transition.loggeomean = lambda: c["trans"].to(DEV, dtype)
+    h.initial.loggeomean = lambda: c["init"].to(DEV, dtype)
+    p, SEzz, SEz0, logZ = h.forward_backward_logits(c["logits"].to(DEV, dtype))
+    tol = 1e-10 if dtype == torch.float64 else TOL32
+    assert_close(p, c["p"], tol, what="p")
+    assert_close(SEzz, c["SEzz"], tol, what="SEzz")
+    assert_close(logZ, c["logZ"], tol, what="logZ")
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 @pytest.mark.parametrize("K,T,lead,batch,ptemp", [(4, 30, (5, 3), (), 1.0), (25, 20, (7,), (), 6.0), (3, 17, (4, 2), (2,), 1.0),
                                                   (2, 9, (1,), (), 1.0), (9, 12, (70,), (), 2.0)])
-def test_hmm_forward_backward_vs_restatement(K, T, lead, batch, ptemp, dtype):
+def test_hmm_forward_backward_vs_oracle(K, T, lead, batch, ptemp, dtype):
     from pyvbmp_amd import ops
     g = torch.Generator().manual_seed(K * 7 + T)
     logits = (2.0 * torch.randn((T,) + lead + (K,), generator=g, dtype=torch.float64)).to(dtype)

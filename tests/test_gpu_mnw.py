@@ -210,3 +210,151 @@ def test_weighted_matsum_cols(S, inner, NB, dtype):
     ref = (W.to(dtype).double().T @ C.to(dtype).double().reshape(S, -1)).reshape((NB,) + inner)
     assert out.shape == (NB,) + inner
     assert_close(out, ref, 1e-12 if dtype == torch.float64 else 2e-5, what="matsum_cols")
+
+
+# ------------------------------------------------------------------ BASELINE configs[2]: one precision per message
+MNWMSG_CASES = ["msg_32x32", "msg_32x31_pad", "msg_32x32_pad", "msg_16x16_b3", "msg_24x32", "msg_32x20"]
+
+
+def _fitted(c, dtype):
+    """the product class carrying the fitted state stored in the fixture (rounded to `dtype`)"""
+    from pyvbmp_amd.transforms import MatrixNormalWishart
+    batch = tuple(int(v) for v in c["batch_shape"])
+    m = MatrixNormalWishart((int(c["n"]), int(c["p"])), batch, pad_X=bool(int(c["pad_X"])), device=DEV, dtype=dtype)
+    for f in ("mu", "invV", "V", "logdetinvV"):
+        setattr(m, f, c["state_" + f].to(DEV, dtype))
+    for f in ("invU", "U", "nu", "logdet_invU"):
+        setattr(m.invU, f, c["state_invU_" + f].to(DEV, dtype))
+    return m
+
+
+def _msg_tol(dtype):
+    return TOL64 if dtype == torch.float64 else 1e-4  # north_star: 1e-10 fp64 / 1e-4 fp32
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("case", MNWMSG_CASES)
+def test_mnw_messages_per_message_golden(golden, case, dtype):
+    """forward / backward with a precision per message (ref transforms/MatrixNormalWishart.py:303-328, :352-375) against
+    the reference's fp64 outputs, in fp64 at 1e-10 and in fp32 at 1e-4 (the fixture's inputs are float32-representable);
+    msg_32x32 in fp32 is exactly the kernel instance BASELINE configs[2] dispatches to, msg_32x32_pad (internal p = 33)
+    takes the composed route beyond the fused kernel's size"""
+    from pyvbmp_amd import _lib
+    c = golden("mnwmsg")[case]
+    m = _fitted(c, dtype)
+    tol = _msg_tol(dtype)
+    launched = []
+    _lib.launch_hooks = (lambda name: launched.append(name), lambda name: None)
+    try:
+        pY, R = m.forward(_vfd(dtype, invSigma=c["fw_in_invSigma"], invSigmamu=c["fw_in_invSigmamu"]))
+        pX, Rb = m.backward(_vfd(dtype, invSigma=c["bw_in_invSigma"], invSigmamu=c["bw_in_invSigmamu"]),
+                            Res=c["bw_in_Res"].to(DEV, dtype))
+    finally:
+        _lib.launch_hooks = None
+    fused = launched.count("vbmp_mnw_message")
+    assert fused == (0 if case == "msg_32x32_pad" else 2), launched  # the route this case is meant to take
+    assert pY.mu.dtype == dtype and pX.invSigma.dtype == dtype
+    assert_close(pY.mu, c["fw_mu"], tol, what="fw mu")
+    assert_close(pY.Sigma, c["fw_Sigma"], tol, what="fw Sigma")
+    assert_close(R, c["fw_Res"], tol, what="fw Res")
+    assert_close(pX.invSigma, c["bw_invSigma"], tol, what="bw P")
+    assert_close(pX.invSigmamu, c["bw_invSigmamu"], tol, what="bw eta")
+    assert_close(Rb, c["bw_Res"], tol, what="bw Res")
+
+
+def _vfd(dtype, **kw):
+    from pyvbmp_amd.dists import MultivariateNormal_vector_format
+    return MultivariateNormal_vector_format(**{k: v.to(DEV, dtype).clone() for k, v in kw.items()})
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("layout", ["offset", "strided"])
+def test_mnw_messages_generic_instance_golden(golden, layout, dtype, monkeypatch):
+    """the same configs[2] golden through the GENERIC kernel instance of the C-ABI: a precision operand that is not
+    16-byte aligned (offset) or not dense over the messages (strided) cannot take the exact-size tile loads.  The host
+    classes always hand the kernel dense aligned copies, so the operand is passed through as it lies in memory here."""
+    from pyvbmp_amd import ops
+    c = golden("mnwmsg")["msg_32x32"]
+    m = _fitted(c, dtype)
+    tol = _msg_tol(dtype)
+    raw = {}
+
+    def relayout(P):
+        P = P.to(DEV, dtype)
+        N, d = P.shape[0], P.shape[-1]
+        if layout == "offset":
+            out = torch.empty(N * d * d + 1, device=DEV, dtype=dtype)[1:].view(N, d, d)
+        else:
+            out = torch.empty(N, 2, d, d, device=DEV, dtype=dtype)[:, 1]
+        out.copy_(P)
+        assert (out.data_ptr() % 16 != 0) if layout == "offset" else (out.stride(0) == 2 * d * d)
+        raw[out.data_ptr()] = out
+        return out
+    norm2 = ops._norm2
+
+    def passthrough(X, sample_shape, bshape, inner):
+        if X.data_ptr() in raw and len(inner) == 2:
+            return X, X.stride(0), 0  # as it lies: (pointer, element stride per message, shared by the experts)
+        return norm2(X, sample_shape, bshape, inner)
+    monkeypatch.setattr(ops, "_norm2", passthrough)
+    from pyvbmp_amd.dists import MultivariateNormal_vector_format as VF
+    pY, R = m.forward(VF(invSigma=relayout(c["fw_in_invSigma"]), invSigmamu=c["fw_in_invSigmamu"].to(DEV, dtype)))
+    assert_close(pY.mu, c["fw_mu"], tol, what="fw mu")
+    assert_close(pY.Sigma, c["fw_Sigma"], tol, what="fw Sigma")
+    assert_close(R, c["fw_Res"], tol, what="fw Res")
+    pX, Rb = m.backward(VF(invSigma=relayout(c["bw_in_invSigma"]), invSigmamu=c["bw_in_invSigmamu"].to(DEV, dtype)),
+                        Res=c["bw_in_Res"].to(DEV, dtype))
+    assert_close(pX.invSigma, c["bw_invSigma"], tol, what="bw P")
+    assert_close(pX.invSigmamu, c["bw_invSigmamu"], tol, what="bw eta")
+    assert_close(Rb, c["bw_Res"], tol, what="bw Res")
+
+
+def test_mnw_messages_full_size_fp32_properties(golden):
+    """BASELINE configs[2] at full size (262 144 messages, n = p = 32, fp32): size-independent properties of the
+    messages (Sigma_yy symmetric positive definite and >= the noise floor invEinvSigma; backward precision symmetric PD;
+    forward-then-backward consistency of the fused kernels with the composed K1 + GEMM route on a slice) plus the oracle
+    (fp64, reference algorithm) on a strided sample of the messages, at the fp32 tolerance"""
+    from oracle import mnw as omnw
+    from tests.test_oracle_golden import mnwmsg_oracle_state
+    from pyvbmp_amd.dists import MultivariateNormal_vector_format as VF
+    c = golden("mnwmsg")["msg_32x32"]
+    dtype = torch.float32
+    m = _fitted(c, dtype)
+    N, d = 262144, 32
+    g = torch.Generator(device=DEV).manual_seed(0)
+    P = torch.empty(N, d, d, device=DEV, dtype=dtype)
+    for s in range(0, N, 32768):
+        A = torch.randn(32768, d, d + 2, generator=g, device=DEV, dtype=dtype)
+        P[s:s + 32768] = A @ A.transpose(-2, -1) / (d + 2)
+    P.diagonal(dim1=-2, dim2=-1).add_(0.5)
+    eta = torch.randn(N, d, 1, generator=g, device=DEV, dtype=dtype)
+    pY, R = m.forward(VF(invSigma=P, invSigmamu=eta))
+    S = pY.Sigma
+    assert tuple(S.shape) == (N, d, d) and tuple(pY.mu.shape) == (N, d, 1) and tuple(R.shape) == (N,)
+    assert torch.isfinite(S).all() and torch.isfinite(pY.mu).all() and torch.isfinite(R).all()
+    assert float((S - S.transpose(-2, -1)).abs().amax() / S.abs().amax()) < 1e-5
+    floor = m.invEinvSigma()
+    for s in range(0, N, 65536):  # Sigma_yy - invEinvSigma = M S* M' is PSD; Sigma_yy itself PD
+        ev = torch.linalg.eigvalsh((S[s:s + 65536] - floor).double())
+        assert float(ev.min()) > -1e-5 * float(ev.max())
+    pX, Rb = m.backward(VF(invSigma=P, invSigmamu=eta))
+    Q = pX.invSigma
+    assert torch.isfinite(Q).all() and torch.isfinite(pX.invSigmamu).all() and torch.isfinite(Rb).all()
+    assert float((Q - Q.transpose(-2, -1)).abs().amax() / Q.abs().amax()) < 1e-5
+    for s in range(0, N, 65536):
+        assert float(torch.linalg.eigvalsh(Q[s:s + 65536].double()).min()) > 0
+    # oracle on a strided sample
+    idx = torch.arange(0, N, 4099, device=DEV)
+    st = mnwmsg_oracle_state(c, torch.float64)
+    for f in ("mu", "invV", "V", "logdetinvV"):  # the state the fp32 product actually holds
+        st[f] = getattr(m, f).cpu().double()
+    for f in ("invU", "U", "nu", "logdet_invU"):
+        st["W"][f] = getattr(m.invU, f).cpu().double()
+    mu_o, S_o, R_o = omnw.mnw_forward(st, P[idx].cpu().double(), eta[idx].cpu().double())
+    assert_close(pY.mu[idx], mu_o, 1e-4, what="fw mu sample")
+    assert_close(S[idx], S_o, 1e-4, what="fw Sigma sample")
+    assert_close(R[idx], R_o, 1e-4, what="fw Res sample")
+    P_o, e_o, Rb_o = omnw.mnw_backward(st, P[idx].cpu().double(), eta[idx].cpu().double())
+    assert_close(Q[idx], P_o, 1e-4, what="bw P sample")
+    assert_close(pX.invSigmamu[idx], e_o, 1e-4, what="bw eta sample")
+    assert_close(Rb[idx], Rb_o, 1e-4, what="bw Res sample")

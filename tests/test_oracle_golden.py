@@ -336,3 +336,47 @@ def test_mixture_batched(golden):
         assert_close(alpha, c[pre + "alpha"], 1e-9)
         assert_close(st["mu"], c[pre + "mu"], 1e-9)
         assert_close(st["W"]["invU"], c[pre + "invU"], 1e-9)
+
+
+# ---------------------------------------------------------------------- MNW messages with a precision per message (BASELINE configs[2])
+MNWMSG_CASES = ["msg_32x32", "msg_32x31_pad", "msg_32x32_pad", "msg_16x16_b3", "msg_24x32", "msg_32x20"]
+
+
+def mnwmsg_oracle_state(c, dtype=torch.float64):
+    """oracle state of the fitted transform stored by tools/gen_golden.py:mnwmsg_case"""
+    batch = tuple(int(v) for v in c["batch_shape"])
+    st = omnw.mnw_new((int(c["n"]), int(c["p"])), batch, mu_init=c["state_mu"].to(dtype), pad_X=bool(int(c["pad_X"])), dtype=dtype)
+    for f in ("invV", "V", "logdetinvV"):
+        st[f] = c["state_" + f].to(dtype)
+    for f in ("invU", "U", "nu", "logdet_invU"):
+        st["W"][f] = c["state_invU_" + f].to(dtype)
+    return st
+
+
+@pytest.mark.parametrize("case", MNWMSG_CASES)
+def test_mnw_messages_per_message_precision(golden, case):
+    c = golden("mnwmsg")[case]
+    st = mnwmsg_oracle_state(c)
+    mu_y, Syy, R = omnw.mnw_forward(st, c["fw_in_invSigma"].double(), c["fw_in_invSigmamu"].double())
+    assert_close(mu_y, c["fw_mu"], what="fw mu")
+    assert_close(Syy, c["fw_Sigma"], what="fw Sigma")
+    assert_close(R, c["fw_Res"], what="fw Res")
+    P, eta, R = omnw.mnw_backward(st, c["bw_in_invSigma"].double(), c["bw_in_invSigmamu"].double(), Res=c["bw_in_Res"].double())
+    assert_close(P, c["bw_invSigma"], what="bw P")
+    assert_close(eta, c["bw_invSigmamu"], what="bw eta")
+    assert_close(R, c["bw_Res"], what="bw Res")
+
+
+# ---------------------------------------------------------------------- HMM forward-backward
+HMM_CASES = ["hmm_k25_roles", "hmm_k25_roles_ptemp", "hmm_k4", "hmm_k3_b2", "hmm_k9_T1", "hmm_k2_T2"]
+
+
+@pytest.mark.parametrize("case", HMM_CASES)
+def test_hmm_forward_backward(golden, case):
+    from oracle import hmm as ohmm
+    c = golden("hmm")[case]
+    p, SEzz, SEz0, logZ = ohmm.forward_backward(c["logits"], c["trans"], c["init"], float(c["ptemp"]))
+    assert_close(p, c["p"], what="p")
+    assert_close(SEzz, c["SEzz"], what="SEzz")
+    assert_close(SEz0, c["SEz0"], what="SEz0")
+    assert_close(logZ, c["logZ"], what="logZ")

@@ -1189,6 +1189,162 @@ def gen_dmix():
 
 GROUPS["dmix"] = gen_dmix
 
+# ---------------------------------------------------------------------- config 3: MNW messages, one precision per message
+def mnwmsg_case(b, name, n, p, batch, pad_X, gen, N=64, Nfit=96):
+    """BASELINE configs[2] shape (forward / backward with a precision PER MESSAGE) from a fitted transform: the stored
+    post-update state is the test's input, so that a float32 run of the product starts from the same (rounded) state."""
+    b.begin(name)
+    m = transforms.MatrixNormalWishart(event_shape=(n, p), batch_shape=batch, pad_X=pad_X)
+    nb = len(batch)
+    W = torch.randn(batch + (n, p), generator=gen) / p ** 0.5
+    X = torch.randn((Nfit,) + (1,) * nb + (p, 1), generator=gen)
+    Y = W @ X + 0.3 * torch.randn((Nfit,) + batch + (n, 1), generator=gen)
+    m.raw_update(X.expand((Nfit,) + batch + (p, 1)), Y, lr=1.0)
+    b.put("n", n)
+    b.put("p", p)
+    b.put("pad_X", int(pad_X))
+    b.put("batch_shape", np.array(batch, dtype=np.int64))
+    snap_mnw(b, m, "state_")
+    # message inputs are float32-representable (stored as float32: half the fixture, and a float32 run reads them exactly)
+    f32 = lambda t: t.float().double()
+    px_P = f32(rand_spd((N,) + (1,) * nb, p, gen))
+    px_eta = f32(torch.randn((N,) + (1,) * nb + (p, 1), generator=gen))
+    b.put("fw_in_invSigma", px_P.float())
+    b.put("fw_in_invSigmamu", px_eta.float())
+    pYm, Res = m.forward(dists.MultivariateNormal_vector_format(invSigma=px_P.clone(), invSigmamu=px_eta.clone()))
+    b.put("fw_mu", pYm.mu)
+    b.put("fw_Sigma", pYm.Sigma)
+    b.put("fw_Res", Res)
+    py_P = f32(rand_spd((N,) + (1,) * nb, n, gen))
+    py_eta = f32(torch.randn((N,) + (1,) * nb + (n, 1), generator=gen))
+    b.put("bw_in_invSigma", py_P.float())
+    b.put("bw_in_invSigmamu", py_eta.float())
+    Res_in = f32(torch.randn((N,) + batch, generator=gen))
+    b.put("bw_in_Res", Res_in.float())
+    pXb, Res = m.backward(dists.MultivariateNormal_vector_format(invSigma=py_P.clone(), invSigmamu=py_eta.clone()), Res=Res_in)
+    b.put("bw_invSigma", pXb.invSigma)
+    b.put("bw_invSigmamu", pXb.invSigmamu)
+    b.put("bw_Res", Res)
+
+
+def gen_mnwmsg():
+    b = Book()
+    gen = torch.Generator().manual_seed(3232)
+    torch.manual_seed(32)
+    mnwmsg_case(b, "msg_32x32", 32, 32, (), False, gen)            # configs[2] itself
+    mnwmsg_case(b, "msg_32x31_pad", 32, 31, (), True, gen, N=16)         # bias column: internal p = 32, message dim 31
+    mnwmsg_case(b, "msg_32x32_pad", 32, 32, (), True, gen, N=8)   # internal p = 33: beyond the fused kernel (composed route)
+    mnwmsg_case(b, "msg_16x16_b3", 16, 16, (3,), False, gen, N=24)
+    mnwmsg_case(b, "msg_24x32", 24, 32, (), False, gen, N=12)      # n != p, padded output rows
+    mnwmsg_case(b, "msg_32x20", 32, 20, (), False, gen, N=12)
+    b.save("mnwmsg")
+
+
+GROUPS["mnwmsg"] = gen_mnwmsg
+
+# ---------------------------------------------------------------------- HMM forward-backward (models/HMM.py:72-105)
+def hmm_case(b, name, K, T, lead, batch, ptemp, gen, mask=None, scale=2.0):
+    import models  # reference
+    b.begin(name)
+    obs = dists.NormalInverseWishart(event_shape=(2,), batch_shape=batch + (K,))  # only its batch shape is used here
+    h = models.HMM(obs, transition_mask=mask, ptemp=ptemp)
+    h.transition.alpha = h.transition.alpha_0 + 3.0 * torch.rand(batch + (K, K), generator=gen) * (1.0 if mask is None else mask)
+    h.initial.alpha = h.initial.alpha_0 + 2.0 * torch.rand(batch + (K,), generator=gen)
+    logits = scale * torch.randn((T,) + lead + batch + (K,), generator=gen)
+    for k, v in (("K", K), ("T", T), ("ptemp", ptemp)):
+        b.put(k, v)
+    b.put("batch_shape", np.array(batch, dtype=np.int64))
+    b.put("logits", logits)
+    b.put("trans", h.transition.loggeomean())
+    b.put("init", h.initial.loggeomean())
+    if mask is not None:
+        b.put("mask", mask)
+    p, SEzz, SEz0, logZ = h.forward_backward_logits(logits.clone())
+    b.put("p", p)
+    b.put("SEzz", SEzz)
+    b.put("SEz0", SEz0)
+    b.put("logZ", logZ)
+
+
+def gen_hmm():
+    import contextlib
+    import io
+
+    import models  # reference
+    b = Book()
+    gen = torch.Generator().manual_seed(2525)
+    torch.manual_seed(25)
+    with contextlib.redirect_stdout(io.StringIO()):  # the role chain of the flocking DMBD: 25 roles, masked transitions
+        d = models.DynamicMarkovBlanketDiscovery(obs_shape=(12, 4), role_dims=(1, 2, 2), hidden_dims=(4, 4, 4),
+                                                 regression_dim=-1, control_dim=0, number_of_objects=6)
+    role_mask = d.obs_model.transition_mask
+    hmm_case(b, "hmm_k25_roles", 25, 30, (6,), (), 1.0, gen, mask=role_mask)
+    hmm_case(b, "hmm_k25_roles_ptemp", 25, 12, (2, 3), (), 3.0, gen, mask=role_mask, scale=6.0)
+    hmm_case(b, "hmm_k4", 4, 40, (5, 3), (), 1.0, gen)
+    hmm_case(b, "hmm_k3_b2", 3, 17, (4,), (2,), 2.0, gen)
+    hmm_case(b, "hmm_k9_T1", 9, 1, (3,), (), 1.0, gen)
+    hmm_case(b, "hmm_k2_T2", 2, 2, (1,), (), 1.0, gen)
+    b.save("hmm")
+
+
+GROUPS["hmm"] = gen_hmm
+
+# ---------------------------------------------------------------------- config 5: DMBD at the Flocking_example hyper-parameters
+def gen_dmbd_flock():
+    """examples/Flocking_example.py:38 exactly: role_dims=(1,2,2), hidden_dims=(4,4,4), number_of_objects=6,
+    regression_dim=-1, control_dim=0 (hidden 52, 25 roles) on the repo's boids generator (the reference's data file is
+    absent) at T=20, 2 runs, 12 birds.  Only the quantities the test compares are stored (fixture < 1 MB)."""
+    import contextlib
+    import importlib.util
+    import io
+
+    import models  # reference
+    spec = importlib.util.spec_from_file_location("vbmp_synth", os.path.join(os.path.dirname(os.path.abspath(__file__)), "synth.py"))
+    synth = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(synth)
+    b = Book()
+    gen = torch.Generator().manual_seed(66)
+    torch.manual_seed(6)
+    T, S, n_obs, obs_dim = 20, 2, 12, 4
+    b.begin("dmbd_flocking")
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = models.DynamicMarkovBlanketDiscovery(obs_shape=(n_obs, obs_dim), role_dims=(1, 2, 2), hidden_dims=(4, 4, 4),
+                                                 regression_dim=-1, control_dim=0, number_of_objects=6, unique_obs=False)
+    y = synth.boids(T, S, n_obs, gen, device="cpu")
+    b.put("y", y)
+    b.put("A_mask", m.A.mask)
+    b.put("B_X_mask", m.B.X_mask)
+    b.put("role_mask", m.obs_model.transition_mask)
+    b.put("init_x0_mu", m.x0.mu)
+    b.put("init_A_mu", m.A.mu)
+    b.put("init_A_alpha", m.A.invU.gamma.alpha)
+    b.put("init_A_beta", m.A.invU.gamma.beta)
+    b.put("init_B_mu", m.B.mu)
+    b.put("init_B_invU_0", m.B.invU.invU_0)
+    b.put("init_trans_alpha", m.obs_model.transition.alpha)
+    b.put("init_init_alpha", m.obs_model.initial.alpha)
+    for it in (1, 2):
+        with contextlib.redirect_stdout(io.StringIO()):
+            m.update(y, None, None, iters=1, latent_iters=1, lr=1.0)
+        pre = f"it{it}_"
+        b.put(pre + "p", m.obs_model.p)
+        b.put(pre + "NA", m.NA)
+        b.put(pre + "SEzz", m.SEzz)
+        b.put(pre + "SEz0", m.SEz0)
+        b.put(pre + "logZ", m.logZ)
+        b.put(pre + "ELBO", m.ELBO_last)
+        b.put(pre + "px_mu", m.px.mu)
+        b.put(pre + "A_mu", m.A.mu)
+        b.put(pre + "A_beta", m.A.invU.gamma.beta)
+        b.put(pre + "B_mu", m.B.mu)
+        b.put(pre + "B_invU_invU", m.B.invU.invU)
+        b.put(pre + "x0_mu", m.x0.mu)
+        b.put(pre + "trans_alpha", m.obs_model.transition.alpha)
+    b.save("dmbd_flock")
+
+
+GROUPS["dmbd_flock"] = gen_dmbd_flock
+
 
 if __name__ == "__main__":
     want = sys.argv[1:] or list(GROUPS)

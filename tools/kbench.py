@@ -10,6 +10,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch  # noqa: E402
 
 from bench import algorithmic_bytes_per_update, make_inputs  # noqa: E402
@@ -146,24 +147,7 @@ def bench_lds(args):
               f"({prac * T * S / tk[0] / 1e6 / 80:.2f}% of 8 TB/s), minimal-I/O {mini * T * S / tk[0] / 1e6:.1f} GB/s", flush=True)
 
 
-def boids(T, S, n, gen, dt=0.1):
-    """small Couzin/boids-style flock in 2-D: (T, S, n, 4) = positions and velocities of n birds (synthetic
-    stand-in for the reference's missing ./data/flocking.pt)"""
-    dev = "cuda"
-    pos = torch.randn(S, n, 2, generator=gen, device=dev, dtype=torch.float64)
-    vel = torch.randn(S, n, 2, generator=gen, device=dev, dtype=torch.float64) * 0.5
-    out = []
-    for _ in range(T):
-        com = pos.mean(1, keepdim=True)
-        d = pos.unsqueeze(2) - pos.unsqueeze(1)                      # (S,n,n,2)
-        rep = (d / (d.pow(2).sum(-1, keepdim=True) + 0.1)).sum(2)
-        align = vel.mean(1, keepdim=True) - vel
-        vel = vel + dt * (0.5 * (com - pos) + 0.3 * rep + 0.4 * align) + 0.05 * torch.randn(vel.shape, generator=gen, device=dev, dtype=torch.float64)
-        vel = vel / vel.norm(dim=-1, keepdim=True).clamp_min(0.3)
-        pos = pos + dt * vel
-        out.append(torch.cat((pos, vel), -1))
-    y = torch.stack(out)
-    return (y - y.mean((0, 1, 2), keepdim=True)) / y.std()
+from synth import boids  # noqa: E402  (tools/synth.py)
 
 
 def bench_dmbd(args):
