@@ -1,18 +1,31 @@
 #!/usr/bin/env python3
-"""Headline benchmark: conjugate updates/s of batched NormalInverseWishart.ss_update
-(BASELINE.json config 2: batch = 1e6 per GPU, D = 16, fp64, lr = 1, default priors).
+"""Benchmarks of the conjugate-update hot path on MI355X.  Default = the headline, BASELINE.json configs[1]:
+conjugate updates/s of batched NormalInverseWishart.ss_update (batch = 1e6, D = 16, fp64, lr = 1, default priors).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--dim D] [--dtype f64|f32] [--lr LR]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload niw|mnw_fwd|mnw_bwd|lds|dmbd]
+                    [--scaling weak|strong] [--batch B] [--dim D] [--dtype f64|f32] [--lr LR]
 
-One "step" = one pass of the hot path over the whole synthetic batch through the product class
-(pyvbmp_amd.dists.NormalInverseWishart.ss_update -> libvbmp_hip.so vbmp_niw_ss_update_*), inputs
-already resident in HBM.  N > 1 is launched by torch.distributed.run (one rank per GPU); the batch
-axis is sharded (independent posteriors, no data-path collective) => weak scaling.
+One "step" = one pass of the hot path over the whole synthetic batch through the product classes (-> libvbmp_hip.so),
+inputs already resident in HBM.  Workloads (BASELINE.json configs):
+  niw      configs[1]  NormalInverseWishart.ss_update, B = 1e6, D = 16, fp64           (K2, HBM-bound)   [default]
+  mnw_fwd  configs[2]  MatrixNormalWishart.forward, 262144 messages, n = p = 32, fp32  (K7)
+  mnw_bwd  configs[2]  MatrixNormalWishart.backward, same sizes                        (K8)
+  lds      configs[3]  LinearDynamicalSystems E-step, T = 1000, 4096 series, hidden 6  (K9)
+  dmbd     configs[4]  DynamicMarkovBlanketDiscovery VB iteration, Flocking_example hyper-parameters, series sharded
+                       over the ranks with packed all-reduces of the statistics (RCCL)
+
+N > 1: one rank per GPU.  Either launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment)
+or, from a plain shell, `python bench.py --gpus N` spawns the N ranks itself (before touching the GPU) and relays rank 0's
+JSON line.  --scaling weak (default): the per-GPU batch is fixed; strong: the batch is the TOTAL and is cut into N
+contiguous slices.  Independent posteriors / messages need no data-path collective; dmbd (and lds at N > 1) exchange
+their packed statistics through torch.distributed (backend nccl = RCCL over xGMI).
 Rank 0 prints ONE JSON line (metric/value/... + roofline + cpu_baseline).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,7 +35,8 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+FP32_VALU_TFLOPS = 157.3   # dense fp32 vector peak (MI355X_MICROARCH.md)
 
 
 def algorithmic_bytes_per_update(D, itemsize, lr):
@@ -49,72 +63,428 @@ def make_inputs(B, D, dtype, device, n=32, seed=0):
     return SExx, SEx, N
 
 
-def cpu_baseline(D, dtype, lr, target_s=12.0):
-    """The CPU oracle (torch-CPU restatement of the reference's op sequence, pinned to the reference by
-    tests/golden) timed on this host's cores on a bounded sample of the same workload."""
-    from oracle import niw as oniw
-    threads = torch.get_num_threads()
-    Bc = 20_000
-    SExx, SEx, N = make_inputs(Bc, D, dtype, "cpu")
-    st = oniw.niw_new((D,), (Bc,), dtype=dtype)
+def _bounded(run, size0, target_s, cap):
+    """time run(size) on a sample scaled so that the timed part takes about target_s; returns (size, best seconds)"""
     t0 = time.perf_counter()
-    oniw.niw_ss_update(st, SExx, SEx, N, lr=lr, beta=None)
+    run(size0)
     t_small = time.perf_counter() - t0
-    # scale the sample so that the timed part is roughly target_s, capped for memory (~17 GB RSS at 1e6)
-    Bc = int(min(500_000, max(20_000, Bc * target_s / 2.0 / max(t_small, 1e-3))))
-    SExx, SEx, N = make_inputs(Bc, D, dtype, "cpu")
-    st = oniw.niw_new((D,), (Bc,), dtype=dtype)
+    size = int(min(cap, max(size0, size0 * target_s / 2.0 / max(t_small, 1e-3))))
     best = float("inf")
     for _ in range(2):
         t0 = time.perf_counter()
-        oniw.niw_ss_update(st, SExx, SEx, N, lr=lr, beta=None)
+        run(size)
         best = min(best, time.perf_counter() - t0)
-    return {"value": Bc / best, "unit": "updates/s", "cores": threads, "kind": "port",
-            "sample": f"oracle.niw.niw_ss_update on B={Bc} of the same synthetic batch (D={D}, {str(dtype)[6:]}, "
-                      f"lr={lr}), best of 2, {best:.2f} s; host has {os.cpu_count()} logical cpus"}
+    return size, best
+
+
+def _local_count(total_or_per_gpu, rank, world, scaling):
+    from pyvbmp_amd.parallel import shard_bounds
+    if scaling == "weak":
+        return total_or_per_gpu
+    lo, hi = shard_bounds(total_or_per_gpu, rank, world)
+    return hi - lo
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+class NiwWorkload:
+    """BASELINE configs[1] (the headline)."""
+    kernel = "vbmp_niw_ss_update"
+    kernel_dev = "k_niw_ss_update"
+
+    def __init__(self, args):
+        self.a = args
+        self.dtype = torch.float64 if args.dtype == "f64" else torch.float32
+        self.dtype_name = args.dtype
+        self.metric = "conjugate updates/sec (batch=1e6, D=16 NIW)"
+        self.unit = "updates/s"
+
+    def setup(self, device, rank, world, scaling):
+        from pyvbmp_amd.dists import NormalInverseWishart
+        a = self.a
+        self.B = B = _local_count(a.batch, rank, world, scaling)
+        self.SExx, self.SEx, self.N = make_inputs(B, a.dim, self.dtype, device, seed=rank)
+        self.q = NormalInverseWishart((a.dim,), (B,), device=device, dtype=self.dtype)
+        self.units = B
+        self.bpu = algorithmic_bytes_per_update(a.dim, 8 if self.dtype == torch.float64 else 4, a.lr)
+        self.bytes_per_launch = self.bpu * B
+        self.launches_per_step = 1
+
+    def step(self):
+        self.q.ss_update(self.SExx, self.SEx, self.N, lr=self.a.lr, beta=None)
+
+    def config(self, world, scaling):
+        a = self.a
+        per = "per GPU" if scaling == "weak" else "in total"
+        return {"workload": f"BASELINE configs[1]: batched NormalInverseWishart.ss_update, batch={a.batch} {per}, "
+                            f"D={a.dim}, {a.dtype}, lr={a.lr}, beta=None, default priors",
+                "batch": a.batch, "batch_is": per, "dim": a.dim, "lr": a.lr, "parallelism": f"batch-sharded x{world}",
+                "collectives_per_step": 0}
+
+    def roofline_extra(self):
+        return {"bytes_per_update": self.bpu}
+
+    def traffic_key(self):
+        a = self.a
+        return f"niw_ss_update_{a.dtype}_D{a.dim}_B{self.B}_lr{a.lr}"
+
+    def cpu_baseline(self, target_s=12.0):
+        """the CPU oracle (torch-CPU restatement of the reference's op sequence, pinned to the reference by tests/golden)
+        timed on this host's cores on a bounded sample of the same workload"""
+        from oracle import niw as oniw
+        a = self.a
+
+        def run(Bc):
+            SExx, SEx, N = make_inputs(Bc, a.dim, self.dtype, "cpu")
+            st = oniw.niw_new((a.dim,), (Bc,), dtype=self.dtype)
+            t0 = time.perf_counter()
+            oniw.niw_ss_update(st, SExx, SEx, N, lr=a.lr, beta=None)
+            return time.perf_counter() - t0
+        t_small = run(20_000)
+        Bc = int(min(500_000, max(20_000, 20_000 * target_s / 2.0 / max(t_small, 1e-3))))  # ~17 GB RSS at 1e6
+        best = min(run(Bc), run(Bc))
+        return {"value": Bc / best, "unit": self.unit, "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"oracle.niw.niw_ss_update on B={Bc} of the same synthetic batch (D={a.dim}, {a.dtype}, lr={a.lr}), "
+                          f"best of 2, {best:.2f} s; host has {os.cpu_count()} logical cpus"}
+
+
+class MnwMessageWorkload:
+    """BASELINE configs[2]: forward / backward messages with one precision per message."""
+    kernel = "vbmp_mnw_message"
+    kernel_dev = "k_mnw_message"
+
+    def __init__(self, args, direction):
+        self.a, self.dir = args, direction
+        self.dtype_name = "f32" if args.dtype_set is None else args.dtype
+        self.dtype = torch.float32 if self.dtype_name == "f32" else torch.float64
+        self.n = self.p = 32 if args.dim_set is None else args.dim
+        self.total = 262144 if args.batch_set is None else args.batch
+        self.metric = f"MatrixNormalWishart {direction} messages/sec (batch=262144, D_in=D_out=32, fp32)"
+        self.unit = "messages/s"
+
+    def _fitted(self, device):
+        """a transform fitted to 4096 synthetic pairs, so that its expectations are generic dense matrices"""
+        from pyvbmp_amd.transforms import MatrixNormalWishart
+        n, p, dt = self.n, self.p, self.dtype
+        g = torch.Generator(device=device).manual_seed(0)
+        torch.manual_seed(0)
+        m = MatrixNormalWishart((n, p), (), device=device, dtype=dt)
+        X = torch.randn(4096, p, 1, generator=g, device=device, dtype=dt)
+        W = torch.randn(n, p, generator=g, device=device, dtype=dt) / p ** 0.5
+        Y = W @ X + 0.3 * torch.randn(4096, n, 1, generator=g, device=device, dtype=dt)
+        m.raw_update(X, Y)
+        return m
+
+    @staticmethod
+    def _messages(N, d, dt, device, seed):
+        g = torch.Generator(device=device).manual_seed(100 + seed)
+        P = torch.empty(N, d, d, device=device, dtype=dt)
+        for s in range(0, N, 32768):
+            e = min(N, s + 32768)
+            A = torch.randn(e - s, d, d + 4, generator=g, device=device, dtype=dt)
+            P[s:e] = A @ A.transpose(-2, -1) / (d + 4)
+        P.diagonal(dim1=-2, dim2=-1).add_(0.5)
+        return P, torch.randn(N, d, 1, generator=g, device=device, dtype=dt)
+
+    def setup(self, device, rank, world, scaling):
+        from pyvbmp_amd.dists import MultivariateNormal_vector_format as VF
+        self.N = N = _local_count(self.total, rank, world, scaling)
+        self.m = self._fitted(device)
+        d = self.p if self.dir == "forward" else self.n
+        P, eta = self._messages(N, d, self.dtype, device, rank)
+        self.msg = VF(invSigma=P, invSigmamu=eta)
+        self.units = N
+        it = 4 if self.dtype == torch.float32 else 8
+        n, p = self.n, self.p
+        self.bpm = (p * p + p + n * n + n + 1) * it  # SURVEY 8(d): 8452 B/msg at n = p = 32 fp32, both directions
+        self.bytes_per_launch = self.bpm * N
+        self.launches_per_step = 1
+        # elimination work per message (flop, 2 per FMA): Gauss-Jordan inverse 2 d^3, quadratic-form elimination 2/3 d^3 each,
+        # sandwich M S M' 4 d^3 (two products)
+        dd = float(d) ** 3
+        self.flop_per_msg = (2 + 0.667 + 4) * dd if self.dir == "forward" else (2 + 3 * 0.667 + 4) * dd
+
+    def step(self):
+        if self.dir == "forward":
+            self.out = self.m.forward(self.msg)
+        else:
+            self.out = self.m.backward(self.msg)
+
+    def config(self, world, scaling):
+        per = "per GPU" if scaling == "weak" else "in total"
+        return {"workload": f"BASELINE configs[2]: MatrixNormalWishart.{self.dir}, {self.total} messages {per}, one precision "
+                            f"per message, D_in=D_out={self.n}, {self.dtype_name}",
+                "messages": self.total, "messages_is": per, "n": self.n, "p": self.p,
+                "parallelism": f"message-sharded x{world}", "collectives_per_step": 0}
+
+    def roofline_extra(self):
+        return {"bytes_per_message": self.bpm, "flop_per_message": self.flop_per_msg}
+
+    def traffic_key(self):
+        return f"mnw_{self.dir}_{self.dtype_name}_n{self.n}_N{self.N}"
+
+    def cpu_baseline(self, target_s=10.0):
+        from oracle import mnw as omnw
+        n, p, dt = self.n, self.p, self.dtype
+        m = self.m
+        st = omnw.mnw_new((n, p), (), mu_init=m.mu.cpu(), dtype=dt)
+        for f in ("invV", "V", "logdetinvV"):
+            st[f] = getattr(m, f).cpu()
+        for f in ("invU", "U", "nu", "logdet_invU"):
+            st["W"][f] = getattr(m.invU, f).cpu()
+        d = p if self.dir == "forward" else n
+        fn = omnw.mnw_forward if self.dir == "forward" else omnw.mnw_backward
+
+        def run(Nc):
+            P, eta = self._messages(Nc, d, dt, "cpu", 7)
+            t0 = time.perf_counter()
+            fn(st, P, eta)
+            return time.perf_counter() - t0
+        t_small = run(2048)
+        Nc = int(min(262144, max(2048, 2048 * target_s / 2.0 / max(t_small, 1e-3))))
+        best = min(run(Nc), run(Nc))
+        return {"value": Nc / best, "unit": self.unit, "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"oracle.mnw.mnw_{self.dir} on {Nc} messages of the same synthetic batch (n=p={n}, {self.dtype_name}), "
+                          f"best of 2, {best:.2f} s; host has {os.cpu_count()} logical cpus"}
+
+
+class LdsWorkload:
+    """BASELINE configs[3]: LDS VB E-step (filter + smoother + time-integrated statistics)."""
+    kernel = "vbmp_lds_smoother"
+    kernel_dev = "k_lds_smoother_g16"
+
+    def __init__(self, args):
+        self.a = args
+        self.dtype_name = args.dtype
+        self.dtype = torch.float64 if args.dtype == "f64" else torch.float32
+        self.T = args.T
+        self.total = 4096 if args.batch_set is None else args.batch
+        self.h = 6
+        self.metric = "LinearDynamicalSystems E-step (t,series)/sec (T=1000, 4096 series, state dim 6)"
+        self.unit = "(t,series)/s"
+
+    def setup(self, device, rank, world, scaling):
+        from pyvbmp_amd.models import LinearDynamicalSystems
+        from tools.synth import lorenz
+        self.S = S = _local_count(self.total, rank, world, scaling)
+        g = torch.Generator(device=device).manual_seed(rank)
+        y = lorenz(self.T, S, g, device=device, dtype=self.dtype)
+        torch.manual_seed(0)
+        self.m = m = LinearDynamicalSystems((6,), self.h, latent_noise='shared', device=device, dtype=self.dtype)
+        if world > 1:
+            from pyvbmp_amd.parallel import SuffStatReducer
+            m.reducer = SuffStatReducer()
+        self.inputs = m.reshape_inputs(y)
+        self.units = self.T * S
+        it = 8 if self.dtype == torch.float64 else 4
+        self.bpu = 1968 // 8 * it  # SURVEY 8(d): practical floor per (t, series) at h = 6, obs 6 (720 B minimal I/O)
+        self.bytes_per_launch = self.bpu * self.units
+        self.launches_per_step = 1
+        self.world = world
+
+    def step(self):
+        m = self.m
+        m.update_latents(*self.inputs)
+        if self.world > 1:
+            m.reduce_statistics()  # the E-step's statistics cross the ranks in ONE packed all-reduce
+
+    def config(self, world, scaling):
+        per = "per GPU" if scaling == "weak" else "in total"
+        return {"workload": f"BASELINE configs[3]: LinearDynamicalSystems.update_latents (VB E-step) on Lorenz data, T={self.T}, "
+                            f"{self.total} series {per}, hidden 6, obs 6, latent_noise='shared', {self.dtype_name}",
+                "T": self.T, "series": self.total, "series_is": per, "hidden": self.h,
+                "parallelism": f"series-sharded x{world}", "collectives_per_step": 0 if world == 1 else 1}
+
+    def roofline_extra(self):
+        return {"bytes_per_t_series": self.bpu, "minimal_io_bytes_per_t_series": 720 // 8 * (8 if self.dtype == torch.float64 else 4)}
+
+    def traffic_key(self):
+        return f"lds_{self.dtype_name}_T{self.T}_S{self.S}"
+
+    def cpu_baseline(self, target_s=10.0):
+        from oracle import lds as olds
+        from oracle import mnw as omnw
+        from oracle import niw as oniw
+        from tools.synth import lorenz
+        m, h, T = self.m, self.h, self.T
+        x0 = oniw.niw_new((h,), (), mu_init=m.x0.mu.cpu().double())
+        A = omnw.mnw_new((h, h + 1), (), mu_init=m.A.mu.cpu().double())
+        obs = omnw.mnw_new((6, h + 1), (), mu_init=m.obs_model.mu.cpu().double())
+        lp = olds.latent_parms(A, h)
+
+        def run(Sc):
+            y = lorenz(T, Sc, torch.Generator().manual_seed(3), device="cpu")
+            yo, uo, ro = olds.reshape_inputs(y, None, None, (6,), 1, 1)
+            t0 = time.perf_counter()
+            sm = olds.smoother(lp, x0, h, yo, uo, ro, obs, 0)
+            olds.latent_stats(sm, yo, uo, ro, (6,), 1, 1, (), 0)
+            return time.perf_counter() - t0
+        t_small = run(16)
+        Sc = int(min(512, max(16, 16 * target_s / 2.0 / max(t_small, 1e-3))))
+        best = run(Sc)
+        return {"value": T * Sc / best, "unit": self.unit, "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"oracle.lds.smoother + latent_stats (fp64) on T={T}, {Sc} series of the same Lorenz data, {best:.2f} s; "
+                          f"host has {os.cpu_count()} logical cpus"}
+
+
+class DmbdWorkload:
+    """BASELINE configs[4]: one DMBD VB iteration at the Flocking_example hyper-parameters, series sharded over ranks."""
+    kernel = "vbmp_lds_smoother"
+    kernel_dev = "k_lds_smoother_blk"
+
+    def __init__(self, args):
+        self.a = args
+        self.dtype_name = args.dtype
+        self.dtype = torch.float64 if args.dtype == "f64" else torch.float32
+        self.T = 100
+        self.total = 20 if args.batch_set is None else args.batch
+        self.n_obs = 12
+        self.metric = "DynamicMarkovBlanketDiscovery VB iteration (t,series)/sec (Flocking hyper-parameters)"
+        self.unit = "(t,series)/s"
+
+    def setup(self, device, rank, world, scaling):
+        from pyvbmp_amd.models import DynamicMarkovBlanketDiscovery
+        from tools.synth import boids
+        self.S = S = _local_count(self.total, rank, world, scaling)
+        g = torch.Generator(device=device).manual_seed(rank)
+        self.y = boids(self.T, S, self.n_obs, g, device=device, dtype=self.dtype)
+        torch.manual_seed(0)  # identical initial state on every rank
+        self.m = m = DynamicMarkovBlanketDiscovery(obs_shape=(self.n_obs, 4), role_dims=(1, 2, 2), hidden_dims=(4, 4, 4),
+                                                   regression_dim=-1, control_dim=0, number_of_objects=6, device=device,
+                                                   dtype=self.dtype)
+        self.reducer = None
+        if world > 1:
+            from pyvbmp_amd.parallel import SuffStatReducer
+            self.reducer = m.reducer = SuffStatReducer()
+        self.h = h = m.hidden_dim
+        self.units = self.T * S
+        it = 8 if self.dtype == torch.float64 else 4
+        # the smoother's own I/O per (t, series): likelihood natural parameters in (h^2 + h), posterior moments out
+        # (mu, invSigmamu: 2h; Sigma, invSigma, Sigma_t_tp1: 3 h^2)
+        self.bpu = (4 * h * h + 3 * h) * it
+        self.bytes_per_launch = self.bpu * self.units
+        self.launches_per_step = 1
+        self.iterations = 0
+
+    def step(self):
+        self.m.update(self.y, None, None, iters=1, latent_iters=1, lr=self.a.dmbd_lr)
+        self.iterations += 1
+
+    def config(self, world, scaling):
+        per = "per GPU" if scaling == "weak" else "in total"
+        cfg = {"workload": f"BASELINE configs[4]: DynamicMarkovBlanketDiscovery.update (one VB iteration) with the Flocking_example "
+                           f"hyper-parameters (role_dims=(1,2,2), hidden_dims=(4,4,4), number_of_objects=6, regression_dim=-1: hidden "
+                           f"{self.h}, 25 roles) on synthetic boids, T={self.T}, {self.total} series {per}, {self.n_obs} observables, "
+                           f"{self.dtype_name}, lr={self.a.dmbd_lr}",
+               "T": self.T, "series": self.total, "series_is": per, "hidden": self.h, "roles": 25,
+               "parallelism": f"series-sharded x{world}",
+               "collectives_per_iteration": (self.reducer.calls / max(self.iterations, 1)) if self.reducer is not None else 0,
+               "elbo_finite": bool(torch.isfinite(self.m.ELBO_last).all())}
+        return cfg
+
+    def roofline_extra(self):
+        return {"bytes_per_t_series": self.bpu, "note": "the smoother (h = 52, block-per-series form) is latency / issue bound, "
+                "not HBM-bound: the fraction is reported for completeness"}
+
+    def traffic_key(self):
+        return f"dmbd_{self.dtype_name}_T{self.T}_S{self.S}"
+
+    def cpu_baseline(self, target_s=10.0):
+        return None  # no CPU restatement of the whole DMBD iteration exists; BASELINE.md quotes the reference's own timing
+
+
+def make_workload(args):
+    w = args.workload
+    if w == "niw":
+        return NiwWorkload(args)
+    if w == "mnw_fwd":
+        return MnwMessageWorkload(args, "forward")
+    if w == "mnw_bwd":
+        return MnwMessageWorkload(args, "backward")
+    if w == "lds":
+        return LdsWorkload(args)
+    if w == "dmbd":
+        return DmbdWorkload(args)
+    raise SystemExit(f"unknown workload {w}")
+
+
+DEFAULT_STEPS = {"niw": (50, 5), "mnw_fwd": (30, 3), "mnw_bwd": (30, 3), "lds": (10, 2), "dmbd": (10, 2)}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    """`python bench.py --gpus N` from a plain shell: spawn the N ranks (one per GPU) as child processes BEFORE this process
+    touches the GPU; rank 0 prints the JSON line on the inherited stdout."""
+    n = args.gpus
+    have = torch.cuda.device_count()  # counting devices does not initialise the GPU
+    if have < n:
+        raise SystemExit(f"--gpus {n} but only {have} GPU(s) visible")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    sys.exit(rc)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1_000_000, help="batch per GPU")
-    ap.add_argument("--dim", type=int, default=16)
-    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="niw", choices=["niw", "mnw_fwd", "mnw_bwd", "lds", "dmbd"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--batch", type=int, default=None, help="independent units (updates / messages / series): per GPU when "
+                    "--scaling weak, in total when strong; default = the BASELINE config's size")
+    ap.add_argument("--dim", type=int, default=None)
+    ap.add_argument("--dtype", default=None, choices=["f64", "f32"])
     ap.add_argument("--lr", type=float, default=1.0)
+    ap.add_argument("--T", type=int, default=1000, help="lds: time steps")
+    ap.add_argument("--dmbd-lr", type=float, default=1.0, dest="dmbd_lr")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    args.batch_set, args.dim_set, args.dtype_set = args.batch, args.dim, args.dtype
+    if args.batch is None:
+        args.batch = 1_000_000
+    if args.dim is None:
+        args.dim = 16
+    if args.dtype is None:
+        args.dtype = "f64"
+    ds, dw = DEFAULT_STEPS[args.workload]
+    args.steps = ds if args.steps is None else args.steps
+    args.warmup = dw if args.warmup is None else args.warmup
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)
+        return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
+    ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        dist.init_process_group(args.backend, device_id=device if args.backend == "nccl" else None)
+        ranks_seen = dist.get_world_size()
 
     from pyvbmp_amd import _lib
     if not os.path.exists(_lib.LIB_PATH):
         import __graft_entry__
         __graft_entry__.build()
-    from pyvbmp_amd.dists import NormalInverseWishart
 
-    dtype = torch.float64 if args.dtype == "f64" else torch.float32
-    B, D = args.batch, args.dim
-    SExx, SEx, N = make_inputs(B, D, dtype, device, seed=rank)
-    q = NormalInverseWishart((D,), (B,), device=device, dtype=dtype)
-
-    def step():
-        q.ss_update(SExx, SEx, N, lr=args.lr, beta=None)
+    wl = make_workload(args)
+    wl.setup(device, rank, world, args.scaling)
 
     def barrier():
         torch.cuda.synchronize()
@@ -123,68 +493,80 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
-    # HIP events recorded by the launch hooks right around the kernel enqueue, on torch's current
+        wl.step()
+    # HIP events recorded by the launch hooks right around the enqueue of the dominant kernel, on torch's current
     # stream (= the stream handed to the C-ABI), so each pair brackets exactly one kernel launch.
     starts, stops = [], []
 
     def before(name):
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record()
-        starts.append(ev)
+        if name == wl.kernel:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            starts.append(ev)
 
     def after(name):
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record()
-        stops.append(ev)
+        if name == wl.kernel:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            stops.append(ev)
 
     barrier()
     _lib.launch_hooks = (before, after)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step()
+        wl.step()
     barrier()
     elapsed = time.perf_counter() - t0
     _lib.launch_hooks = None
-    assert len(starts) == args.steps == len(stops), "one kernel launch per step expected"
-    kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, stops)) / args.steps
+    assert len(starts) == len(stops) == args.steps * wl.launches_per_step, \
+        f"{wl.launches_per_step} launch(es) of {wl.kernel} per step expected, saw {len(starts)} in {args.steps} steps"
+    kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, stops)) / len(starts)
+    units_total = wl.units
     if dist is not None:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
+        u = torch.tensor([wl.units], dtype=torch.float64, device=device)
+        dist.all_reduce(u, op=dist.ReduceOp.SUM)
+        units_total = float(u[0])
 
     if rank == 0:
-        itemsize = 8 if dtype == torch.float64 else 4
-        bpu = algorithmic_bytes_per_update(D, itemsize, args.lr)
-        achieved = bpu * B / (kernel_ms * 1e-3) / 1e9  # GB/s, one launch = B updates
-        traffic = None
+        achieved = wl.bytes_per_launch / (kernel_ms * 1e-3) / 1e9  # GB/s of algorithmic bytes, one launch of rank 0's share
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                key = f"niw_ss_update_{args.dtype}_D{D}_B{B}_lr{args.lr}"
-                traffic = tj.get(key)
+                ent = tj.get(wl.traffic_key())
+                if isinstance(ent, dict):
+                    traffic, traffic_source = ent.get("bytes"), ent.get("source")
+                elif ent is not None:
+                    traffic, traffic_source = ent, tj.get("_source")
             except Exception:
                 traffic = None
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                "kernel": wl.kernel_dev, "kernel_ms": kernel_ms}
+        roof.update(wl.roofline_extra())
+        if "flop_per_message" in roof:
+            tf = roof["flop_per_message"] * wl.units / (kernel_ms * 1e-3) / 1e12
+            roof["valu_fp32"] = {"achieved": tf, "peak": FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_VALU_TFLOPS}
         out = {
-            "metric": "conjugate updates/sec (batch=1e6, D=16 NIW)",
-            "value": world * B * args.steps / elapsed,
-            "unit": "updates/s",
+            "metric": wl.metric,
+            "value": units_total * args.steps / elapsed,
+            "unit": wl.unit,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: batched NormalInverseWishart.ss_update, batch={B} per GPU, "
-                                   f"D={D}, {args.dtype}, lr={args.lr}, beta=None, default priors",
-                       "batch_per_gpu": B, "dim": D, "lr": args.lr, "parallelism": f"batch-sharded x{world}"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_niw_ss_update", "kernel_ms": kernel_ms, "bytes_per_update": bpu},
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": wl.dtype_name, "data": "synthetic", "ranks_seen": ranks_seen,
+            "config": wl.config(world, args.scaling),
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(D, dtype, args.lr)
+            out["cpu_baseline"] = wl.cpu_baseline()
         print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -46,6 +46,8 @@ def shared_matvec(G, Y):
     samples*batch tiny matrix-vector products a broadcasting `@` is lowered to (600 000 of them, 2 ms, for the role
     emissions of the flocking DMBD).  Anything that does not have this shape goes to `@` unchanged."""
     nb = G.dim() - 2
+    if G.shape[-1] == 0 or Y.numel() == 0:
+        return G @ Y  # empty contraction (e.g. no regressors: regression_dim = -1 in DynamicMarkovBlanketDiscovery)
     if nb == 0 and Y.dim() > 2 and Y.shape[-1] == 1 and Y.is_cuda and _k12_pays(Y.numel() // G.shape[-1], G.shape[-1], G.shape[-2]):
         # ONE matrix, very many vectors (the observation messages of an LDS E-step: 4e6 rows of 6): the library GEMM for
         # such a shape runs at a tenth of the memory bandwidth; K12 streams the rows once
@@ -74,7 +76,7 @@ def shared_weighted_sum(P, w):
 def rows_matmul(X, W):
     """X @ W for X = lead + (k,) with very many rows and ONE small W (k, n): K12 (one streaming pass) on the device when
     the library GEMM would be the tall-skinny case it handles poorly (_k12_pays); `@` otherwise."""
-    if W.dim() == 2 and X.is_cuda and X.dim() >= 2 and _k12_pays(X.numel() // W.shape[0], W.shape[0], W.shape[1]):
+    if W.dim() == 2 and X.numel() > 0 and W.numel() > 0 and X.is_cuda and X.dim() >= 2 and _k12_pays(X.numel() // W.shape[0], W.shape[0], W.shape[1]):
         from . import ops
         return ops.rows_affine(X.reshape(-1, W.shape[0]), W.transpose(0, 1)).reshape(tuple(X.shape[:-1]) + (W.shape[1],))
     return X @ W

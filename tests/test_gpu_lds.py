@@ -75,19 +75,9 @@ def test_lds_golden(golden, case, form, smoother_form):
 
 
 def lorenz(T, S, gen, dt=0.01, stride=5):
-    """Euler-integrated Lorenz-63 trajectories (our own generator; same kind of data as simulations/Lorenz.py)."""
-    x = torch.randn(S, 3, generator=gen, dtype=torch.float64) * 5 + torch.tensor([0.0, 0.0, 25.0], dtype=torch.float64)
-    out = []
-    for i in range(T * stride):
-        dx = torch.stack((10.0 * (x[:, 1] - x[:, 0]), x[:, 0] * (28.0 - x[:, 2]) - x[:, 1],
-                          x[:, 0] * x[:, 1] - 8.0 / 3.0 * x[:, 2]), -1)
-        x = x + dt * dx
-        if i % stride == 0:
-            out.append(x.clone())
-    d = torch.stack(out)  # (T, S, 3)
-    v = torch.cat((d[1:] - d[:-1], d[-1:] - d[-2:-1]), 0) / dt / 20.0
-    z = torch.cat((d / 10.0, v), -1)
-    return z - z.mean((0, 1), keepdim=True)
+    """Euler-integrated Lorenz-63 trajectories (our own generator, tools/synth.py; same kind of data as simulations/Lorenz.py)."""
+    from tools.synth import lorenz as _lorenz
+    return _lorenz(T, S, gen, dt, stride, device="cpu")
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-8), (torch.float32, 5e-3)])

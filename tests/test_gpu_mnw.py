@@ -213,7 +213,7 @@ def test_weighted_matsum_cols(S, inner, NB, dtype):
 
 
 # ------------------------------------------------------------------ BASELINE configs[2]: one precision per message
-MNWMSG_CASES = ["msg_32x32", "msg_32x31_pad", "msg_32x32_pad", "msg_16x16_b3", "msg_24x32", "msg_32x20"]
+MNWMSG_CASES = ["msg_32x32", "msg_32x31_pad", "msg_32x32_pad", "msg_16x16_b3", "msg_24x32", "msg_32x20", "msg_8x40"]
 
 
 def _fitted(c, dtype):
@@ -237,8 +237,8 @@ def _msg_tol(dtype):
 def test_mnw_messages_per_message_golden(golden, case, dtype):
     """forward / backward with a precision per message (ref transforms/MatrixNormalWishart.py:303-328, :352-375) against
     the reference's fp64 outputs, in fp64 at 1e-10 and in fp32 at 1e-4 (the fixture's inputs are float32-representable);
-    msg_32x32 in fp32 is exactly the kernel instance BASELINE configs[2] dispatches to, msg_32x32_pad (internal p = 33)
-    takes the composed route beyond the fused kernel's size"""
+    msg_32x32 in fp32 is exactly the kernel instance BASELINE configs[2] dispatches to, msg_8x40 (p = 40) takes the
+    composed route beyond the fused kernel's size"""
     from pyvbmp_amd import _lib
     c = golden("mnwmsg")[case]
     m = _fitted(c, dtype)
@@ -252,7 +252,7 @@ def test_mnw_messages_per_message_golden(golden, case, dtype):
     finally:
         _lib.launch_hooks = None
     fused = launched.count("vbmp_mnw_message")
-    assert fused == (0 if case == "msg_32x32_pad" else 2), launched  # the route this case is meant to take
+    assert fused == (0 if case == "msg_8x40" else 2), launched  # the route this case is meant to take
     assert pY.mu.dtype == dtype and pX.invSigma.dtype == dtype
     assert_close(pY.mu, c["fw_mu"], tol, what="fw mu")
     assert_close(pY.Sigma, c["fw_Sigma"], tol, what="fw Sigma")

@@ -339,7 +339,7 @@ def test_mixture_batched(golden):
 
 
 # ---------------------------------------------------------------------- MNW messages with a precision per message (BASELINE configs[2])
-MNWMSG_CASES = ["msg_32x32", "msg_32x31_pad", "msg_32x32_pad", "msg_16x16_b3", "msg_24x32", "msg_32x20"]
+MNWMSG_CASES = ["msg_32x32", "msg_32x31_pad", "msg_32x32_pad", "msg_16x16_b3", "msg_24x32", "msg_32x20", "msg_8x40"]
 
 
 def mnwmsg_oracle_state(c, dtype=torch.float64):

@@ -1233,10 +1233,11 @@ def gen_mnwmsg():
     torch.manual_seed(32)
     mnwmsg_case(b, "msg_32x32", 32, 32, (), False, gen)            # configs[2] itself
     mnwmsg_case(b, "msg_32x31_pad", 32, 31, (), True, gen, N=16)         # bias column: internal p = 32, message dim 31
-    mnwmsg_case(b, "msg_32x32_pad", 32, 32, (), True, gen, N=8)   # internal p = 33: beyond the fused kernel (composed route)
+    mnwmsg_case(b, "msg_32x32_pad", 32, 32, (), True, gen, N=8)   # internal p = 33, message dim 32
     mnwmsg_case(b, "msg_16x16_b3", 16, 16, (3,), False, gen, N=24)
     mnwmsg_case(b, "msg_24x32", 24, 32, (), False, gen, N=12)      # n != p, padded output rows
     mnwmsg_case(b, "msg_32x20", 32, 20, (), False, gen, N=12)
+    mnwmsg_case(b, "msg_8x40", 8, 40, (), False, gen, N=6)         # p = 40: beyond the fused kernel (composed K1 + GEMM route)
     b.save("mnwmsg")
 
 
