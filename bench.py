@@ -63,20 +63,6 @@ def make_inputs(B, D, dtype, device, n=32, seed=0):
     return SExx, SEx, N
 
 
-def _bounded(run, size0, target_s, cap):
-    """time run(size) on a sample scaled so that the timed part takes about target_s; returns (size, best seconds)"""
-    t0 = time.perf_counter()
-    run(size0)
-    t_small = time.perf_counter() - t0
-    size = int(min(cap, max(size0, size0 * target_s / 2.0 / max(t_small, 1e-3))))
-    best = float("inf")
-    for _ in range(2):
-        t0 = time.perf_counter()
-        run(size)
-        best = min(best, time.perf_counter() - t0)
-    return size, best
-
-
 def _local_count(total_or_per_gpu, rank, world, scaling):
     from pyvbmp_amd.parallel import shard_bounds
     if scaling == "weak":
@@ -416,7 +402,7 @@ def self_launch(args):
     touches the GPU; rank 0 prints the JSON line on the inherited stdout."""
     n = args.gpus
     have = torch.cuda.device_count()  # counting devices does not initialise the GPU
-    if have < n:
+    if have < n and not args.oversubscribe:
         raise SystemExit(f"--gpus {n} but only {have} GPU(s) visible")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -447,6 +433,8 @@ def main():
     ap.add_argument("--T", type=int, default=1000, help="lds: time steps")
     ap.add_argument("--dmbd-lr", type=float, default=1.0, dest="dmbd_lr")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--oversubscribe", action="store_true", help="rehearsal on a box with fewer GPUs than ranks: ranks share "
+                    "the cards round-robin (use with --backend gloo; RCCL wants one GPU per rank); never for reported numbers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     args.batch_set, args.dim_set, args.dtype_set = args.batch, args.dim, args.dtype
@@ -468,6 +456,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    if args.oversubscribe:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -559,6 +549,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": wl.dtype_name, "data": "synthetic", "ranks_seen": ranks_seen,
+            "transport": None if world == 1 else (args.backend + (" (ranks share GPUs: rehearsal)" if args.oversubscribe else "")),
             "config": wl.config(world, args.scaling),
             "roofline": roof,
         }

@@ -25,17 +25,48 @@ def shard_bounds(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+class _Packed():
+    """one persistent flat buffer + the views of its slots (one slot per statistic of a given exchange)"""
+
+    def __init__(self, shapes, dtype, device):
+        sizes = [int(torch.Size(sh).numel()) for sh in shapes]
+        self.flat = torch.zeros(sum(sizes), dtype=dtype, device=device)
+        self.views, off = [], 0
+        for sh, n in zip(shapes, sizes):
+            self.views.append(self.flat[off:off + n].view(sh))
+            off += n
+
+
 class SuffStatReducer():
-    """Packs a list of statistic tensors into one flat buffer, sums it over the process group with a single
-    all-reduce and hands the tensors back in their original shapes."""
+    """Sums a list of statistic tensors over the process group with a SINGLE all-reduce of one packed buffer.
+
+    The buffer is persistent: it is laid out once per exchange signature (shapes, dtype, device of the statistics -- an
+    exchange of a VB iteration has the same signature every iteration) and reused, so that an iteration neither
+    concatenates nor splits fresh tensors.  The statistics are written into their slots with one multi-tensor copy, the
+    flat buffer is reduced in place, and the returned tensors are the slots themselves: they stay valid until the next
+    exchange with the same signature (callers rebind their attributes every iteration, as the reference's classes do).
+    `slots(...)` hands the slot views out beforehand for producers that can write their result straight into the
+    packed buffer."""
 
     def __init__(self, group=None):
         self.group = group
-        self.calls = 0  # number of collectives issued (tests assert: one per VB iteration)
+        self.calls = 0  # number of collectives issued (tests assert: one per exchange)
+        self._packed = {}
 
     @property
     def world_size(self):
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def _buffer(self, shapes, dtype, device):
+        key = (tuple(tuple(sh) for sh in shapes), dtype, str(device))
+        pk = self._packed.get(key)
+        if pk is None:
+            pk = self._packed[key] = _Packed(key[0], dtype, device)
+        return pk
+
+    def slots(self, shapes, dtype, device):
+        """views into the persistent packed buffer of this signature, in order; fill them, then `all_reduce(slots)`"""
+        return list(self._buffer(shapes, dtype, device).views)
 
     def all_reduce(self, tensors):
         tensors = [t if isinstance(t, torch.Tensor) else torch.as_tensor(t) for t in tensors]
@@ -44,12 +75,10 @@ class SuffStatReducer():
         dt = tensors[0].dtype
         for t in tensors:
             dt = torch.promote_types(dt, t.dtype)
-        flat = torch.cat([t.reshape(-1).to(dt) for t in tensors])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        pk = self._buffer([t.shape for t in tensors], dt, tensors[0].device)
+        todo = [(v, t) for v, t in zip(pk.views, tensors) if t.data_ptr() != v.data_ptr() or t.dtype != dt]
+        if todo:  # statistics that were not produced in place: one multi-tensor copy into the slots
+            torch._foreach_copy_([v for v, _ in todo], [t.expand(v.shape) for v, t in todo])
+        dist.all_reduce(pk.flat, op=dist.ReduceOp.SUM, group=self.group)
         self.calls += 1
-        out, off = [], 0
-        for t in tensors:
-            n = t.numel()
-            out.append(flat[off:off + n].reshape(t.shape).to(t.dtype))
-            off += n
-        return out
+        return [v if t.dtype == dt else v.to(t.dtype) for v, t in zip(pk.views, tensors)]

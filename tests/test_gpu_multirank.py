@@ -1,0 +1,74 @@
+"""Real multi-process runs of the sharded product paths: one process per rank, torch.distributed.
+
+* `test_sharded_paths_two_ranks`: tests/multirank_worker.py on 2 ranks.  With >= 2 GPUs visible the backend is nccl
+  (= RCCL over xGMI, one GPU per rank); on a one-GPU box the two ranks share the card and exchange through gloo on
+  device tensors -- same product code, same SuffStatReducer, same kernels, only the transport differs.
+* `test_bench_self_launch_two_ranks`: `python bench.py --gpus 2` from a plain environment (no RANK / WORLD_SIZE): the
+  parent spawns the ranks itself and rank 0 prints one JSON line with N > 1."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _plain_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    return env
+
+
+@pytest.mark.timeout(600)
+def test_sharded_paths_two_ranks():
+    world = 2
+    backend = "nccl" if torch.cuda.device_count() >= world else "gloo"
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(_plain_env(), RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), VBMP_TEST_BACKEND=backend)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multirank_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=500)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
+        assert "sharded == single-rank" in o
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("workload,scaling", [("niw", "strong"), ("dmbd", "weak"), ("lds", "weak")])
+def test_bench_self_launch_two_ranks(workload, scaling):
+    """bench.py spawns its own ranks; on a one-GPU box the rehearsal shares the card (--oversubscribe, gloo)"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", workload,
+           "--scaling", scaling, "--no-cpu-baseline"]
+    if workload == "niw":
+        cmd += ["--batch", "200000"]
+    if workload == "lds":
+        cmd += ["--batch", "512", "--T", "200"]
+    if torch.cuda.device_count() < 2:
+        cmd += ["--oversubscribe", "--backend", "gloo"]
+    r = subprocess.run(cmd, env=_plain_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["scaling"] == scaling
+    assert out["value"] > 0 and out["roofline"]["kernel_ms"] > 0
+    if workload == "dmbd":
+        assert out["config"]["collectives_per_iteration"] == 2  # two data-dependent exchanges, each one packed all-reduce
+    if workload == "lds":
+        assert out["config"]["collectives_per_step"] == 1
+    if workload == "niw":
+        assert out["config"]["collectives_per_step"] == 0 and out["config"]["batch_is"] == "in total"
