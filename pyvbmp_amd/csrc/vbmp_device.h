@@ -37,6 +37,12 @@ __device__ __forceinline__ double readlane_any(double v, int lane) {
   return u.d;
 }
 
+// hazard pad in front of a GROUP of DPP FMAs (a whole row update).  Empty: the rows a group reads through its DPP operand
+// were written at least a pivot step earlier; that no VALU write of a source register lands within 2 wait states of its
+// DPP read is proven on the final ISA by tools/check_dpp_hazards.py (tests/test_dpp_hazards.py), not assumed.
+#ifndef VBMP_GROUP_PAD
+#define VBMP_GROUP_PAD ""
+#endif
 #define VBMP_DPP16 "row_newbcast:%c[src] row_mask:0xf bank_mask:0xf"
 #define VBMP_DPP4 "quad_perm:[%c[src],%c[src],%c[src],%c[src]] row_mask:0xf bank_mask:0xf"
 
@@ -111,7 +117,7 @@ __device__ __forceinline__ void fmac_bcast(float& acc, float v, float f) {
 template <int G, int SRC>
 __device__ __forceinline__ void fmac_bcast4(double* acc, const double* piv, double f) {
   if constexpr (G == 16) {
-    asm volatile("s_nop 1\n\t"
+    asm volatile(VBMP_GROUP_PAD
                  "v_fmac_f64_dpp %[a0], %[p0], %[f] " VBMP_DPP16 "\n\t"
                  "v_fmac_f64_dpp %[a1], %[p1], %[f] " VBMP_DPP16 "\n\t"
                  "v_fmac_f64_dpp %[a2], %[p2], %[f] " VBMP_DPP16 "\n\t"
@@ -126,7 +132,7 @@ __device__ __forceinline__ void fmac_bcast4(double* acc, const double* piv, doub
 template <int G, int SRC>
 __device__ __forceinline__ void fmac_bcast4(float* acc, const float* piv, float f) {
   if constexpr (G == 16) {
-    asm volatile("s_nop 1\n\t"
+    asm volatile(VBMP_GROUP_PAD
                  "v_fmac_f32_dpp %[a0], %[p0], %[f] " VBMP_DPP16 "\n\t"
                  "v_fmac_f32_dpp %[a1], %[p1], %[f] " VBMP_DPP16 "\n\t"
                  "v_fmac_f32_dpp %[a2], %[p2], %[f] " VBMP_DPP16 "\n\t"
@@ -134,7 +140,7 @@ __device__ __forceinline__ void fmac_bcast4(float* acc, const float* piv, float 
                  : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3])
                  : [p0] "v"(piv[0]), [p1] "v"(piv[1]), [p2] "v"(piv[2]), [p3] "v"(piv[3]), [f] "v"(f), [src] "n"(SRC));
   } else if constexpr (G == 4) {
-    asm volatile("s_nop 1\n\t"
+    asm volatile(VBMP_GROUP_PAD
                  "v_fmac_f32_dpp %[a0], %[p0], %[f] " VBMP_DPP4 "\n\t"
                  "v_fmac_f32_dpp %[a1], %[p1], %[f] " VBMP_DPP4 "\n\t"
                  "v_fmac_f32_dpp %[a2], %[p2], %[f] " VBMP_DPP4 "\n\t"
@@ -152,7 +158,7 @@ __device__ __forceinline__ void fmac_bcast4(float* acc, const float* piv, float 
 template <int G, int SRC>
 __device__ __forceinline__ void fmac_self4(double* acc, double f) {
   if constexpr (G == 16) {
-    asm volatile("s_nop 1\n\t"
+    asm volatile(VBMP_GROUP_PAD
                  "v_fmac_f64_dpp %[a0], %[a0], %[f] " VBMP_DPP16 "\n\t"
                  "v_fmac_f64_dpp %[a1], %[a1], %[f] " VBMP_DPP16 "\n\t"
                  "v_fmac_f64_dpp %[a2], %[a2], %[f] " VBMP_DPP16 "\n\t"
@@ -167,7 +173,7 @@ __device__ __forceinline__ void fmac_self4(double* acc, double f) {
 template <int G, int SRC>
 __device__ __forceinline__ void fmac_self4(float* acc, float f) {
   if constexpr (G == 16) {
-    asm volatile("s_nop 1\n\t"
+    asm volatile(VBMP_GROUP_PAD
                  "v_fmac_f32_dpp %[a0], %[a0], %[f] " VBMP_DPP16 "\n\t"
                  "v_fmac_f32_dpp %[a1], %[a1], %[f] " VBMP_DPP16 "\n\t"
                  "v_fmac_f32_dpp %[a2], %[a2], %[f] " VBMP_DPP16 "\n\t"
@@ -175,7 +181,7 @@ __device__ __forceinline__ void fmac_self4(float* acc, float f) {
                  : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3])
                  : [f] "v"(f), [src] "n"(SRC));
   } else if constexpr (G == 4) {
-    asm volatile("s_nop 1\n\t"
+    asm volatile(VBMP_GROUP_PAD
                  "v_fmac_f32_dpp %[a0], %[a0], %[f] " VBMP_DPP4 "\n\t"
                  "v_fmac_f32_dpp %[a1], %[a1], %[f] " VBMP_DPP4 "\n\t"
                  "v_fmac_f32_dpp %[a2], %[a2], %[f] " VBMP_DPP4 "\n\t"
@@ -190,7 +196,7 @@ __device__ __forceinline__ void fmac_self4(float* acc, float f) {
 // eight at a time (18 asm operands): halves the number of hazard pads per row
 template <int G, int SRC>
 __device__ __forceinline__ void fmac_self8(double* acc, double f) {
-  asm volatile("s_nop 1\n\t"
+  asm volatile(VBMP_GROUP_PAD
                "v_fmac_f64_dpp %[a0], %[a0], %[f] " VBMP_DPP16 "\n\t"
                "v_fmac_f64_dpp %[a1], %[a1], %[f] " VBMP_DPP16 "\n\t"
                "v_fmac_f64_dpp %[a2], %[a2], %[f] " VBMP_DPP16 "\n\t"
@@ -205,7 +211,7 @@ __device__ __forceinline__ void fmac_self8(double* acc, double f) {
 }
 template <int G, int SRC>
 __device__ __forceinline__ void fmac_self8(float* acc, float f) {
-  asm volatile("s_nop 1\n\t"
+  asm volatile(VBMP_GROUP_PAD
                "v_fmac_f32_dpp %[a0], %[a0], %[f] " VBMP_DPP16 "\n\t"
                "v_fmac_f32_dpp %[a1], %[a1], %[f] " VBMP_DPP16 "\n\t"
                "v_fmac_f32_dpp %[a2], %[a2], %[f] " VBMP_DPP16 "\n\t"
