@@ -87,7 +87,7 @@ class Mixture():
         if graphed and not verbose and (self.reducer is None or self.reducer.world_size == 1):
             from .. import graph
             key = (X.data_ptr(), tuple(X.shape), X.dtype, float(lr))
-            graph.run_iterations(self, lambda: self.update(X, iters=1, lr=lr), iters, key)
+            graph.run_iterations(self, lambda m: m.update(X, iters=1, lr=lr), iters, key)
             return
         for i in range(iters):
             if self.reducer is not None:

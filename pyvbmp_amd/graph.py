@@ -17,8 +17,18 @@ Restrictions (checked where possible, and capture fails loudly otherwise): the i
 the data tensors passed to it must stay alive and in place.
 """
 import gc
+import weakref
 
 import torch
+
+# Destroying a HIP graph while a stream is capturing aborts the process.  Graphs therefore never die during a capture:
+# (1) a GraphedStep holds its model only weakly and gets the model passed into its step function, so there is no
+# model -> cache -> GraphedStep -> closure -> model cycle and a graph's lifetime ends deterministically with its model
+# (or with close()), not whenever the cyclic collector runs; (2) a GraphedStep that is finalised while some capture is
+# in progress (the step under capture dropped the last reference to another model) parks its graph here until that
+# capture has ended; (3) the collector is paused for the duration of a capture as a last line of defence.
+_capture_depth = 0
+_graveyard = []
 
 
 def _walk(obj, path, out, seen):
@@ -65,11 +75,18 @@ def state_tensors(model):
 
 
 class GraphedStep():
-    """graph = GraphedStep(model, lambda: model.update(X, iters=1)); graph.run(n) == n eager iterations."""
+    """graph = GraphedStep(model, lambda m: m.update(X, iters=1)); graph.run(n) == n eager iterations.
+    `step` (and `post`) receive the model as their argument: they must not close over it (see the note on lifetimes)."""
 
     def __init__(self, model, step, warmup=2, post=None):
         """post: optional eager epilogue run after every iteration (bookkeeping whose shapes grow, e.g. an ELBO trace)"""
-        self.model, self.step, self.post = model, step, post
+        global _capture_depth
+        self._model = weakref.ref(model)
+        self._step, self._post = step, post
+        self.graph = None
+        # bound methods as LOCALS only (a stored one would tie this object into a cycle with itself)
+        step = self._run_step
+        post = self._run_post if post is not None else None
         dev = next((_get(o, k).device for (o, k) in state_tensors(model).values()), None)
         assert dev is not None and dev.type == "cuda", "GraphedStep needs a model whose state lives on the GPU"
         self.device = dev
@@ -94,16 +111,47 @@ class GraphedStep():
         gc.collect()
         gc_was_on = gc.isenabled()
         gc.disable()
+        _capture_depth += 1
         try:
             self._capture(model, step, before, static)
         finally:
+            _capture_depth -= 1
             if gc_was_on:
                 gc.enable()
+            if _capture_depth == 0:
+                del _graveyard[:]  # graphs whose owners went away during the capture are released now
         self.static = static
         self.iterations = warmup + 1  # the capture pass does not execute; accounted for by the first replay below
         self.graph.replay()
         if post is not None:
             post()
+
+    def _run_step(self):
+        self._step(self.model)
+
+    def _run_post(self):
+        if self._post is not None:
+            self._post(self.model)
+
+    @property
+    def model(self):
+        m = self._model()
+        if m is None:
+            raise RuntimeError("the model of this GraphedStep no longer exists")
+        return m
+
+    def close(self):
+        """release the HIP graph and its memory pool now (deferred to the end of a capture that is in progress)"""
+        g, self.graph = self.graph, None
+        self.static = {}
+        if g is not None and _capture_depth > 0:
+            _graveyard.append(g)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
 
     def _capture(self, model, step, before, static):
         with torch.cuda.graph(self.graph):
@@ -145,14 +193,22 @@ class GraphedStep():
     def run(self, iters=1):
         for _ in range(iters):
             self.graph.replay()
-            if self.post is not None:
-                self.post()
+            self._run_post()
         self.iterations += iters
         return self
 
 
+def close(model):
+    """drop the cached graph of a model explicitly (its HIP graph and private memory pool are released)"""
+    cache = model.__dict__.get("_vbmp_graphs")
+    if cache:
+        for g in list(cache.values()):
+            g.close()
+        cache.clear()
+
+
 def run_iterations(model, step, iters, key, warmup=2, post=None):
-    """`iters` VB iterations of `step()` (one iteration per call) through a cached GraphedStep; iterations that the
+    """`iters` VB iterations of `step(model)` (one iteration per call) through a cached GraphedStep; iterations that the
     construction of the graph already performed (warm-up + first replay) count towards `iters`.  The graph is
     cached on the model under `key` (data pointer / shape / hyper-parameters of the call): a different key builds
     a new graph."""
@@ -162,11 +218,11 @@ def run_iterations(model, step, iters, key, warmup=2, post=None):
     if g is None:
         if iters < warmup + 1:
             for _ in range(iters):
-                step()
+                step(model)
                 if post is not None:
-                    post()
+                    post(model)
             return
-        cache.clear()  # one graph (and one private memory pool) per model at a time
+        close(model)  # one graph (and one private memory pool) per model at a time
         g = cache[key] = GraphedStep(model, step, warmup=warmup, post=post)
         done = warmup + 1
     else:

@@ -147,7 +147,7 @@ class LinearDynamicalSystems():
         if graphed and not verbose and (self.reducer is None or self.reducer.world_size == 1):
             from .. import graph
             key = tuple((t.data_ptr(), tuple(t.shape), t.dtype) if t is not None else None for t in (y, u, r, p)) + (float(lr),)
-            graph.run_iterations(self, lambda: self.update(y, u, r, p, iters=1, lr=lr), iters, key)
+            graph.run_iterations(self, lambda m: m.update(y, u, r, p, iters=1, lr=lr), iters, key)
             return
         L = torch.full((), -torch.inf, device=self.device, dtype=self.dtype)
         L_last = L

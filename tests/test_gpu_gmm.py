@@ -285,3 +285,49 @@ def test_gmm_graphed_update_matches_eager():
     assert_close(b.pi.alpha, a.pi.alpha, 1e-9, what="alpha")
     assert_close(b.p, a.p, 1e-9, what="p")
     assert_close(b.ELBO(), a.ELBO(), 1e-9, what="ELBO")
+
+
+def test_graph_lifetime_is_deterministic_and_survives_a_delete_during_capture():
+    """(1) no reference cycle: dropping the last reference to a graphed model releases its GraphedStep at once (no
+    collector run); (2) a graphed model whose last reference disappears WHILE another model's iteration is being captured
+    must not take its HIP graph down mid-capture (that aborts the process): the graph is parked until the capture ends"""
+    import gc
+    import weakref
+
+    from pyvbmp_amd import graph
+    from pyvbmp_amd.models import GaussianMixtureModel
+    g = torch.Generator().manual_seed(4)
+    X = torch.randn(500, 2, generator=g, dtype=torch.float64).to(DEV)
+    gc.collect()
+    gc.disable()
+    try:
+        a = GaussianMixtureModel(3, 2, device=DEV, dtype=torch.float64)
+        a.update(X, iters=4, lr=1.0, graphed=True)
+        step_ref = weakref.ref(next(iter(a.__dict__["_vbmp_graphs"].values())))
+        model_ref = weakref.ref(a)
+        del a
+        assert model_ref() is None and step_ref() is None, "a graphed model must not sit in a reference cycle"
+
+        victim = [GaussianMixtureModel(3, 2, device=DEV, dtype=torch.float64)]
+        victim[0].update(X, iters=4, lr=1.0, graphed=True)
+        vref = weakref.ref(victim[0])
+        calls = []
+
+        def step(m):
+            calls.append(graph._capture_depth)
+            if graph._capture_depth > 0 and victim:
+                victim.pop()  # last reference to a graphed model goes away in the middle of this capture
+                assert vref() is None and len(graph._graveyard) == 1
+            m.update(X, iters=1, lr=1.0)
+        torch.manual_seed(8)
+        b = GaussianMixtureModel(3, 2, device=DEV, dtype=torch.float64)
+        torch.manual_seed(8)
+        ref = GaussianMixtureModel(3, 2, device=DEV, dtype=torch.float64)
+        graph.run_iterations(b, step, 5, key="k")
+        assert calls == [0, 0, 1] and not victim and not graph._graveyard
+        ref.update(X, iters=5, lr=1.0)
+        assert_close(b.dist.mu, ref.dist.mu, 1e-9, what="mu after the interrupted capture")
+        graph.close(b)
+        assert not b.__dict__["_vbmp_graphs"]
+    finally:
+        gc.enable()
