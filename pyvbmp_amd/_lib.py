@@ -90,6 +90,7 @@ def _sig_mnw_msg(T):
 
 
 MNW_MAX_DIM = 32
+MAX_DIM = 64  # VBMP_MAX_DIM: K1 / K2 / K3a matrix size per wave
 
 
 def _sig_hmm(T):
@@ -210,5 +211,8 @@ def call(fn, name, *args):
 
 def check(rc, name):
     if rc != 0:
-        raise VbmpHipError(f"{name} failed with code {rc} "
-                           f"({'bad argument' if rc == -1 else 'HIP launch failure' if rc == -2 else 'unknown'})")
+        why = {-1: "bad argument: a null pointer, a negative size, or a size beyond the kernel's limit -- matrices D <= 64 "
+                   "(K1 / K2 / K3a), message dims <= 32 (K7 / K8), <= 64 states (K11), <= 64 row entries (K12), <= 65535 "
+                   "experts / components per launch; see INTEGRATION.md, section Limits",
+               -2: "HIP launch failure"}.get(rc, "unknown")
+        raise VbmpHipError(f"{name} failed with code {rc} ({why})")

@@ -44,6 +44,10 @@ def spd_inv_logdet(A, want_logdet=True, nonspd=None):
     assert A.shape[-2] == D
     bshape = tuple(A.shape[:-2])
     B = _prod(bshape)
+    if D > L.MAX_DIM:
+        # beyond the one-wave-per-matrix kernels (VBMP_MAX_DIM = 64): the device library's factorisations (rocSOLVER through
+        # torch.linalg, still on the GPU); Tensor.logdet keeps the reference's NaN / -inf semantics
+        return torch.linalg.inv(A), (torch.logdet(A) if want_logdet else None)
     Ac = A.contiguous()
     Ainv = torch.empty_like(Ac)
     logdet = torch.empty(bshape, dtype=A.dtype, device=dev) if want_logdet else None
@@ -218,12 +222,25 @@ def weighted_moments(X, pv, n_sample_dims, mat_batch):
     p2 = None
     if pv is not None:
         p2 = pv.to(dt).expand(sample_shape + mat_batch).reshape(S, Bo, Bi).contiguous()
-    nB = Bo * Bi
-    buf = torch.zeros(nB * (1 + D + D * D), dtype=dt, device=dev)
-    Nk, SEx, SExx = buf[:nB], buf[nB:nB * (1 + D)], buf[nB * (1 + D):]
-    if S > 0 and nB > 0:
-        fn = getattr(lib, "vbmp_weighted_moments_" + L.suffix(dt))
-        L.call(fn, "vbmp_weighted_moments", L.ptr(X2), L.ptr(p2), S, Bo, Bi, D, L.ptr(Nk), L.ptr(SEx), L.ptr(SExx), L.stream_ptr(dev))
+    fn = getattr(lib, "vbmp_weighted_moments_" + L.suffix(dt))
+
+    def launch(Xc, pc, bo, bi):
+        nB = bo * bi
+        buf = torch.zeros(nB * (1 + D + D * D), dtype=dt, device=dev)
+        Nk, SEx, SExx = buf[:nB], buf[nB:nB * (1 + D)], buf[nB * (1 + D):]
+        if S > 0 and nB > 0:
+            L.call(fn, "vbmp_weighted_moments", L.ptr(Xc), L.ptr(pc), S, bo, bi, D, L.ptr(Nk), L.ptr(SEx), L.ptr(SExx), L.stream_ptr(dev))
+        return Nk.reshape(bo, bi), SEx.reshape(bo, bi, D), SExx.reshape(bo, bi, D, D)
+    MAXI = 65535  # inner components per launch (grid.y of the kernel): a longer component axis goes in slices
+    if Bi <= MAXI:
+        Nk, SEx, SExx = launch(X2, p2, Bo, Bi)
+    else:
+        parts = []
+        for c0 in range(0, Bi, MAXI):
+            c1 = min(Bi, c0 + MAXI)
+            pc = None if p2 is None else p2[:, :, c0:c1].contiguous()
+            parts.append(launch(X2[:, c0:c1].contiguous(), pc, Bo, c1 - c0))
+        Nk, SEx, SExx = (torch.cat([q[i] for q in parts], dim=1) for i in range(3))
     return Nk.reshape(mat_batch), SEx.reshape(mat_batch + (D,)), SExx.reshape(mat_batch + (D, D))
 
 

@@ -181,7 +181,10 @@ class MatrixNormalWishart():
         latency per DMBD iteration at hidden 52), its blocked Cholesky a few dozen launches, and the solutions agree
         to rounding."""
         L, info = torch.linalg.cholesky_ex(K, check_errors=False)
-        return torch.cholesky_solve(rhs.unsqueeze(-1), L).squeeze(-1)
+        sol = torch.cholesky_solve(rhs.unsqueeze(-1), L).squeeze(-1)
+        # a system that is not numerically positive definite (the reference's LU would still return something) must not
+        # pass silently: its solution becomes NaN, on the device (no host synchronisation), and surfaces in the ELBO
+        return torch.where((info == 0).unsqueeze(-1), sol, torch.full_like(sol, float("nan")))
 
     def _constrain_mean(self, mu, invV, V_new):
         """The posterior mean under the constraint mu[~mask] = 0, i.e. the minimiser of tr[(M - mu)' E[R] (M - mu) invV]

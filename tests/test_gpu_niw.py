@@ -280,3 +280,30 @@ def test_niw_full_size_properties():
     assert_close(W.invU[idx], st["W"]["invU"], what="invU sample")
     assert_close(W.U[idx], st["W"]["U"], what="U sample")
     assert_close(W.logdet_invU[idx], st["W"]["logdet_invU"], what="logdet sample")
+
+
+def test_raw_update_dense_batch_beyond_one_launch():
+    """NormalInverseWishart.raw_update with a DENSE sample per batch element over a batch longer than one launch's
+    component axis (65535): ops.weighted_moments slices the axis; against the closed-form moments"""
+    from pyvbmp_amd import ops
+    S, B, D = 3, 70001, 4
+    g = torch.Generator(device=DEV).manual_seed(2)
+    X = torch.randn(S, B, D, generator=g, dtype=torch.float64, device=DEV)
+    p = torch.rand(S, B, generator=g, dtype=torch.float64, device=DEV)
+    Nk, SEx, SExx = ops.weighted_moments(X, p, 1, (B,))
+    assert_close(Nk, p.sum(0), 1e-13, what="N")
+    assert_close(SEx, (p.unsqueeze(-1) * X).sum(0), 1e-13, what="SEx")
+    assert_close(SExx, torch.einsum("sb,sbi,sbj->bij", p, X, X), 1e-13, what="SExx")
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_spd_inv_logdet_beyond_kernel_size_takes_the_device_library(dtype):
+    from pyvbmp_amd import ops
+    g = torch.Generator().manual_seed(80)
+    A = torch.randn(3, 80, 90, generator=g, dtype=torch.float64)
+    P = (A @ A.transpose(-2, -1) / 90 + 0.5 * torch.eye(80, dtype=torch.float64))
+    Ai, ld = ops.spd_inv_logdet(P.to(DEV, dtype))
+    assert Ai.is_cuda and Ai.dtype == dtype
+    tol = 1e-10 if dtype == torch.float64 else 1e-4
+    assert_close(Ai, torch.linalg.inv(P), tol, what="inverse")
+    assert_close(ld, torch.logdet(P), tol, what="logdet")
