@@ -536,6 +536,7 @@ def main():
                 traffic = None
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                "traffic_key": wl.traffic_key(),
                 "kernel": wl.kernel_dev, "kernel_ms": kernel_ms}
         roof.update(wl.roofline_extra())
         if "flop_per_message" in roof:
