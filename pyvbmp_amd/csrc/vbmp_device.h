@@ -43,6 +43,14 @@ __device__ __forceinline__ double readlane_any(double v, int lane) {
 #ifndef VBMP_GROUP_PAD
 #define VBMP_GROUP_PAD ""
 #endif
+// ... in front of a group that reads ITS OWN destination row through the DPP operand (the compiler has been seen to
+// place a register copy of that row right in front of such a group), and in front of a single DPP FMA
+#ifndef VBMP_SELF_PAD
+#define VBMP_SELF_PAD VBMP_GROUP_PAD
+#endif
+#ifndef VBMP_SINGLE_PAD
+#define VBMP_SINGLE_PAD "s_nop 1\n\t"
+#endif
 #define VBMP_DPP16 "row_newbcast:%c[src] row_mask:0xf bank_mask:0xf"
 #define VBMP_DPP4 "quad_perm:[%c[src],%c[src],%c[src],%c[src]] row_mask:0xf bank_mask:0xf"
 
@@ -97,7 +105,7 @@ __device__ __forceinline__ float xfma(float a, float b, float c) { return __buil
 template <int G, int SRC>
 __device__ __forceinline__ void fmac_bcast(double& acc, double v, double f) {
   if constexpr (G == 16) {
-    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %[a], %[v], %[f] " VBMP_DPP16 : [a] "+v"(acc) : [v] "v"(v), [f] "v"(f), [src] "n"(SRC));
+    asm volatile(VBMP_SINGLE_PAD "v_fmac_f64_dpp %[a], %[v], %[f] " VBMP_DPP16 : [a] "+v"(acc) : [v] "v"(v), [f] "v"(f), [src] "n"(SRC));
   } else {
     acc = xfma(bcast<G, SRC>(v), f, acc);
   }
@@ -105,9 +113,9 @@ __device__ __forceinline__ void fmac_bcast(double& acc, double v, double f) {
 template <int G, int SRC>
 __device__ __forceinline__ void fmac_bcast(float& acc, float v, float f) {
   if constexpr (G == 16) {
-    asm volatile("s_nop 1\n\tv_fmac_f32_dpp %[a], %[v], %[f] " VBMP_DPP16 : [a] "+v"(acc) : [v] "v"(v), [f] "v"(f), [src] "n"(SRC));
+    asm volatile(VBMP_SINGLE_PAD "v_fmac_f32_dpp %[a], %[v], %[f] " VBMP_DPP16 : [a] "+v"(acc) : [v] "v"(v), [f] "v"(f), [src] "n"(SRC));
   } else if constexpr (G == 4) {
-    asm volatile("s_nop 1\n\tv_fmac_f32_dpp %[a], %[v], %[f] " VBMP_DPP4 : [a] "+v"(acc) : [v] "v"(v), [f] "v"(f), [src] "n"(SRC));
+    asm volatile(VBMP_SINGLE_PAD "v_fmac_f32_dpp %[a], %[v], %[f] " VBMP_DPP4 : [a] "+v"(acc) : [v] "v"(v), [f] "v"(f), [src] "n"(SRC));
   } else {
     acc = xfma(bcast<G, SRC>(v), f, acc);
   }
@@ -158,7 +166,7 @@ __device__ __forceinline__ void fmac_bcast4(float* acc, const float* piv, float 
 template <int G, int SRC>
 __device__ __forceinline__ void fmac_self4(double* acc, double f) {
   if constexpr (G == 16) {
-    asm volatile(VBMP_GROUP_PAD
+    asm volatile(VBMP_SELF_PAD
                  "v_fmac_f64_dpp %[a0], %[a0], %[f] " VBMP_DPP16 "\n\t"
                  "v_fmac_f64_dpp %[a1], %[a1], %[f] " VBMP_DPP16 "\n\t"
                  "v_fmac_f64_dpp %[a2], %[a2], %[f] " VBMP_DPP16 "\n\t"
@@ -173,7 +181,7 @@ __device__ __forceinline__ void fmac_self4(double* acc, double f) {
 template <int G, int SRC>
 __device__ __forceinline__ void fmac_self4(float* acc, float f) {
   if constexpr (G == 16) {
-    asm volatile(VBMP_GROUP_PAD
+    asm volatile(VBMP_SELF_PAD
                  "v_fmac_f32_dpp %[a0], %[a0], %[f] " VBMP_DPP16 "\n\t"
                  "v_fmac_f32_dpp %[a1], %[a1], %[f] " VBMP_DPP16 "\n\t"
                  "v_fmac_f32_dpp %[a2], %[a2], %[f] " VBMP_DPP16 "\n\t"
@@ -181,7 +189,7 @@ __device__ __forceinline__ void fmac_self4(float* acc, float f) {
                  : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3])
                  : [f] "v"(f), [src] "n"(SRC));
   } else if constexpr (G == 4) {
-    asm volatile(VBMP_GROUP_PAD
+    asm volatile(VBMP_SELF_PAD
                  "v_fmac_f32_dpp %[a0], %[a0], %[f] " VBMP_DPP4 "\n\t"
                  "v_fmac_f32_dpp %[a1], %[a1], %[f] " VBMP_DPP4 "\n\t"
                  "v_fmac_f32_dpp %[a2], %[a2], %[f] " VBMP_DPP4 "\n\t"
@@ -196,7 +204,7 @@ __device__ __forceinline__ void fmac_self4(float* acc, float f) {
 // eight at a time (18 asm operands): halves the number of hazard pads per row
 template <int G, int SRC>
 __device__ __forceinline__ void fmac_self8(double* acc, double f) {
-  asm volatile(VBMP_GROUP_PAD
+  asm volatile(VBMP_SELF_PAD
                "v_fmac_f64_dpp %[a0], %[a0], %[f] " VBMP_DPP16 "\n\t"
                "v_fmac_f64_dpp %[a1], %[a1], %[f] " VBMP_DPP16 "\n\t"
                "v_fmac_f64_dpp %[a2], %[a2], %[f] " VBMP_DPP16 "\n\t"
@@ -211,7 +219,7 @@ __device__ __forceinline__ void fmac_self8(double* acc, double f) {
 }
 template <int G, int SRC>
 __device__ __forceinline__ void fmac_self8(float* acc, float f) {
-  asm volatile(VBMP_GROUP_PAD
+  asm volatile(VBMP_SELF_PAD
                "v_fmac_f32_dpp %[a0], %[a0], %[f] " VBMP_DPP16 "\n\t"
                "v_fmac_f32_dpp %[a1], %[a1], %[f] " VBMP_DPP16 "\n\t"
                "v_fmac_f32_dpp %[a2], %[a2], %[f] " VBMP_DPP16 "\n\t"
