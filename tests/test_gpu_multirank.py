@@ -72,3 +72,23 @@ def test_bench_self_launch_two_ranks(workload, scaling):
         assert out["config"]["collectives_per_step"] == 1
     if workload == "niw":
         assert out["config"]["collectives_per_step"] == 0 and out["config"]["batch_is"] == "in total"
+
+
+@pytest.mark.timeout(600)
+def test_bench_under_torch_distributed_run():
+    """the driver's own launch line for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` (ranks read RANK / LOCAL_RANK / WORLD_SIZE from the
+    environment); on a one-GPU box as a rehearsal with the ranks sharing the card over gloo"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--batch", "200000", "--no-cpu-baseline"]
+    if torch.cuda.device_count() < 2:
+        cmd += ["--oversubscribe", "--backend", "gloo"]
+    r = subprocess.run(cmd, env=_plain_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["scaling"] == "weak" and out["steps"] == 3
+    assert out["metric"].startswith("conjugate updates/sec") and out["unit"] == "updates/s"
+    assert out["value"] > 0 and 0 < out["roofline"]["frac"] < 1.2
