@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VBMP_ABI_VERSION 3
+#define VBMP_ABI_VERSION 4
 int vbmp_abi_version(void);
 
 /* K1 -- Ainv = A^-1 and logdet = log det A of B symmetric positive definite matrices.
@@ -176,11 +176,16 @@ int vbmp_tsum_outer_f32(const float* a, int64_t sa_t, int64_t sa_s, int da, cons
  *     q3 = e3' (P + Add2_b)^-1 e3     ld3 = logdet(P + Add2_b)            (only when Add2 != NULL)
  *     ovec = M_b v   (m) ;            omat = C_b + sign * M_b Sm M_b^T   (m x m)
  *     q4 = w' omat^-1 w, ld4 = logdet omat,  w = ovec + cvec_b            (only when cvec != NULL)
+ *   Schur mode (e3 != NULL and cvec != NULL with Add2 == NULL): q3 and ld3 refer to the matrix
+ *     P + Add1_b + sign * M_b' C_b^-1 M_b  (the other Schur complement of the joint matrix [[A, .], [., C]]) and are
+ *     obtained WITHOUT eliminating it:  q3 = e3' Sm e3 + t' omat^-1 t  with t = M_b Sm e3,  and scal[5] = ld2 + ld4
+ *     = ld3 + logdet C_b -- the caller subtracts the per-expert constant logdet C_b.
  *   forward : P = P_x, e1 = eta_x, e2 = shifted eta, Add1 = n V, M = E[A], C = invEinvSigma, sign = +1 (d = p, m = n)
  *             Res = -q1/2 + q2/2 - (ld2 - ld1)/2
- *   backward: P = P_y, e1 = eta_y, e2 = j_y, Add1 = E[R], Add2 = E[R] - G H^-1 G', e3 = eta_y + G H^-1 j_x,
- *             M = G' = E[RA]', C = H = E[A'RA], sign = -1, cvec = j_x  (d = n, m = p):  omat = invSigma_x,
- *             ovec + cvec = invSigmamu_x.
+ *   backward: P = P_y, e1 = eta_y, e2 = j_y, Add1 = E[R], e3 = eta_y + G H^-1 j_x, M = G' = E[RA]', C = H = E[A'RA],
+ *             sign = -1, cvec = j_x  (d = n, m = p):  omat = invSigma_x, ovec + cvec = invSigmamu_x; the q3 / ld3 terms of
+ *             the marginal precision E[R] - G H^-1 G' + P_y either in Schur mode (Add2 = NULL, one elimination fewer) or
+ *             with that matrix's constant part passed as Add2.
  * P, e1, e2, e3: element (s,b) at base + s*st_s + b*st_b (strides in elements, 0 = shared).  Add1, Add2 (NB,d,d),
  * M (NB,m,d), C (NB,m,m), cvec (NB,m) dense.  Outputs dense: ovec (S,NB,m), omat (S,NB,m,m),
  * scal (S,NB,8) = [q1, ld1, q2, ld2, q3, ld3, q4, ld4].

@@ -16,7 +16,7 @@ _c_i64 = ctypes.c_int64
 _c_int = ctypes.c_int
 _c_ptr = ctypes.c_void_p
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 

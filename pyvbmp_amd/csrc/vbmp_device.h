@@ -633,4 +633,51 @@ __device__ __forceinline__ T elim_quad(T (&a)[R][Dp], T (&e)[R], int lig, LogDet
   return qacc;
 }
 
+// the same elimination carrying TWO right-hand sides: returns e^T A^-1 e and writes f^T A^-1 f to qf
+template <typename T, int Dp, int G, int R>
+__device__ __forceinline__ T elim_quad2(T (&a)[R][Dp], T (&e)[R], T (&f)[R], int lig, LogDet<T>& ld, T& qf) {
+  static_assert(R * G == Dp, "rows per lane x lanes per matrix must cover the padded dim");
+  T qe = T(0), qq = T(0);
+  static_for<0, Dp>([&](auto K) {
+    constexpr int k = decltype(K)::value;
+    constexpr int src = k % G, slot = k / G;
+    const bool owner = (G == 1) || (lig == src);
+    const T d = bcast<G, src>(a[slot][k]);
+    ld.mul(d);
+    const T p = rcp_nr(d);
+    const T ek = e[slot], fk = f[slot];
+    qe += owner ? ek * ek * p : T(0);
+    qq += owner ? fk * fk * p : T(0);
+    static_for<0, R>([&](auto Q) {
+      constexpr int q = (decltype(Q)::value + slot + 1) % R;  // rows of the pivot slot last (DPP read-after-write)
+      const int row = lig + G * q;
+      const T nf = (row > k) ? -(a[q][k] * p) : T(0);
+      fmac_bcast<G, src>(e[q], e[slot], nf);
+      fmac_bcast<G, src>(f[q], f[slot], nf);
+      constexpr int c0 = (k + 1) / 4;
+      if constexpr (Dp % 4 == 0) {
+#pragma unroll
+        for (int c = c0; c < Dp / 4; ++c) {
+          if constexpr (q == slot)
+            fmac_self4<G, src>(&a[q][4 * c], nf);
+          else
+            fmac_bcast4<G, src>(&a[q][4 * c], &a[slot][4 * c], nf);
+        }
+      } else {
+#pragma unroll
+        for (int j = k + 1; j < Dp; ++j) a[q][j] = xfma(bcast<G, src>(a[slot][j]), nf, a[q][j]);
+      }
+    });
+  });
+  if constexpr (G > 1) {
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) {
+      qe += __shfl_xor(qe, off, G);
+      qq += __shfl_xor(qq, off, G);
+    }
+  }
+  qf = qq;
+  return qe;
+}
+
 }  // namespace vbmp

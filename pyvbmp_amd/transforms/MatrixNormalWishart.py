@@ -426,13 +426,14 @@ class MatrixNormalWishart():
                 G1, H11, jy = G, H, etay
                 jx = torch.zeros(tuple(H.shape[:-1]) + (1,), device=self.device, dtype=self.dtype)
                 J11 = 0.0
-            GHinv = G1 @ ops.spd_inverse(H11)                       # per expert
-            K = Rm - GHinv @ _T(G1)
-            eta_y = jy + GHinv @ jx
-            ovec, Pxx, sc = ops.mnw_message(Py, etay.squeeze(-1), jy.squeeze(-1), eta_y.squeeze(-1), Rm, K, _T(G1), H11,
+            H11inv, ld_H = ops.spd_inv_logdet(H11)                  # per expert
+            eta_y = jy + (G1 @ H11inv) @ jx
+            # the marginal precision of y, Rm - G H^-1 G' + P_y, is never eliminated: its log-determinant and quadratic
+            # form follow from the two eliminations the kernel runs anyway (Schur mode: scal[4] = q3, scal[5] = ld3 + ld_H)
+            ovec, Pxx, sc = ops.mnw_message(Py, etay.squeeze(-1), jy.squeeze(-1), eta_y.squeeze(-1), Rm, None, _T(G1), H11,
                                             jx.squeeze(-1), -1.0, bshape)
             eta_x = ovec.unsqueeze(-1) + jx
-            R = Res + 0.5 * (-sc[..., 0] + sc[..., 1] + sc[..., 4] - sc[..., 5] + sc[..., 6] - sc[..., 7]) \
+            R = Res + 0.5 * (-sc[..., 0] + sc[..., 1] + sc[..., 4] - (sc[..., 5] - ld_H) + sc[..., 6] - sc[..., 7]) \
                 + 0.5 * self.ElogdetinvSigma() - 0.5 * J11 + 0.5 * px_dim * _LOG2PI
             return MultivariateNormal_vector_format(invSigma=Pxx, invSigmamu=eta_x, logdetinvSigma=sc[..., 7]), R
         Pxx, eta_x, R = self._marginalise(pY, +1.0, Res)
