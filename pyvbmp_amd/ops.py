@@ -12,8 +12,26 @@ import torch
 from . import _lib as L
 
 
+CHECK_SPD = False  # pyvbmp_amd.debug.check_spd(): read the kernels' non-SPD counter back after every K1 / K2 / K2a launch
+
+
 def _prod(shape):
     return int(math.prod(shape))
+
+
+def _spd_counter(dev, given):
+    """the device counter handed to the kernel: the caller's, or a fresh one under debug.check_spd()"""
+    if given is not None or not CHECK_SPD:
+        return given, False
+    return torch.zeros(1, dtype=torch.int32, device=dev), True
+
+
+def _spd_verify(counter, own, what):
+    if own:
+        n = int(counter.item())  # synchronises: debug mode only
+        if n:
+            raise L.VbmpHipError(f"{what}: {n} matrices with a non-positive pivot (not symmetric positive definite); the "
+                                 "elimination does not pivot and their log-determinants are NaN / -inf as in the reference")
 
 
 def batch_operand(t, batch_shape, inner_shape):
@@ -52,8 +70,10 @@ def spd_inv_logdet(A, want_logdet=True, nonspd=None):
     Ainv = torch.empty_like(Ac)
     logdet = torch.empty(bshape, dtype=A.dtype, device=dev) if want_logdet else None
     if B > 0:
+        nonspd, own = _spd_counter(dev, nonspd)
         fn = getattr(lib, "vbmp_spd_inv_logdet_" + L.suffix(A.dtype))
         L.call(fn, "vbmp_spd_inv_logdet", L.ptr(Ac), D * D, L.ptr(Ainv), L.ptr(logdet), B, D, L.ptr(nonspd), L.stream_ptr(dev))
+        _spd_verify(nonspd, own, "spd_inv_logdet")
     return Ainv, logdet
 
 
@@ -88,9 +108,11 @@ def wishart_ss_update(SExx, N, invU0, nu0, invU_old, nu_old, lr, nonspd=None):
         suf = L.suffix(dt)
         fn = getattr(lib, "vbmp_wishart_ss_update_" + suf)
         cT = L.DTYPES[suf][1]
+        nonspd, own = _spd_counter(dev, nonspd)
         L.call(fn, "vbmp_wishart_ss_update", L.ptr(SExx_c), sS, L.ptr(N_c), sN, L.ptr(i0), si0, L.ptr(n0), sn0, L.ptr(io), sio, L.ptr(no), sno,
                    cT(float(lr)), L.ptr(invU), L.ptr(nu), L.ptr(U), L.ptr(logdet), B, D, L.ptr(nonspd),
                    L.stream_ptr(dev))
+        _spd_verify(nonspd, own, "wishart_ss_update")
     return invU, nu, U, logdet
 
 
@@ -133,10 +155,12 @@ def niw_ss_update(SExx, SEx, N, lam0, mu0, invU0, nu0, lam_old, mu_old, invU_old
         suf = L.suffix(dt)
         fn = getattr(lib, "vbmp_niw_ss_update_" + suf)
         cT = L.DTYPES[suf][1]
+        nonspd, own = _spd_counter(dev, nonspd)
         L.call(fn, "vbmp_niw_ss_update", L.ptr(SExx_c), sS, L.ptr(SEx_c), sx, L.ptr(N_c), sN, L.ptr(l0), sl0, L.ptr(m0), sm0, L.ptr(i0), si0,
                    L.ptr(n0), sn0, L.ptr(lo), slo, L.ptr(mo), smo, L.ptr(io), sio, L.ptr(no), sno, cT(float(lr)),
                    L.ptr(lam), L.ptr(mu), L.ptr(invU), L.ptr(nu), L.ptr(U), L.ptr(logdet), B, D,
                    1 if fixed_precision else 0, L.ptr(nonspd), L.stream_ptr(dev))
+        _spd_verify(nonspd, own, "niw_ss_update")
     return lam, mu, invU, nu, U, logdet
 
 

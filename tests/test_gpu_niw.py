@@ -307,3 +307,17 @@ def test_spd_inv_logdet_beyond_kernel_size_takes_the_device_library(dtype):
     tol = 1e-10 if dtype == torch.float64 else 1e-4
     assert_close(Ai, torch.linalg.inv(P), tol, what="inverse")
     assert_close(ld, torch.logdet(P), tol, what="logdet")
+
+
+def test_debug_check_spd_raises_on_an_indefinite_matrix():
+    """pyvbmp_amd.debug.check_spd(): the kernels' non-SPD counter is read back; without it the reference's silent NaN"""
+    from pyvbmp_amd import _lib, debug, ops
+    A = torch.eye(5, dtype=torch.float64, device=DEV).repeat(7, 1, 1)
+    A[3, 2, 2] = -1.0
+    Ai, ld = ops.spd_inv_logdet(A)            # default: silent, like Tensor.logdet
+    assert torch.isnan(ld[3]) and torch.isfinite(ld[[0, 1, 2, 4, 5, 6]]).all()
+    with debug.check_spd():
+        ops.spd_inv_logdet(A[:3])             # all positive definite: passes
+        with pytest.raises(_lib.VbmpHipError, match="1 matrices"):
+            ops.spd_inv_logdet(A)
+    assert ops.CHECK_SPD is False

@@ -47,3 +47,14 @@ def test_rows_matmul_is_matmul_off_the_device():
     X = torch.randn(5, 7, 3, generator=g, dtype=torch.float64)
     W = torch.randn(3, 4, generator=g, dtype=torch.float64)
     assert torch.equal(rows_matmul(X, W), X @ W)
+
+
+def test_k12_routing_threshold():
+    """where shared_matvec / rows_matmul hand a tall-skinny product to K12 instead of the library GEMM (measured on MI355X,
+    tools/exp/rows_time.py: K12 wins 5-6x for k, n <= 9 at >= 1e5 rows and still at 16 x 16; rocBLAS wins from 32 x 32 in
+    fp32): at least 16384 rows and k * n <= 256"""
+    from pyvbmp_amd._common import _k12_pays
+    assert _k12_pays(4_096_000, 6, 6) and _k12_pays(16384, 16, 16) and _k12_pays(100_000, 1, 64) and _k12_pays(100_000, 9, 9)
+    assert not _k12_pays(16383, 6, 6)            # too few rows: launch-bound either way, the library call is fine
+    assert not _k12_pays(4_096_000, 32, 32)      # the library GEMM is faster (fp32 64 x 64: 39 against 249 us)
+    assert not _k12_pays(100_000, 16, 17)
