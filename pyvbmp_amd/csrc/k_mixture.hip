@@ -539,11 +539,15 @@ template <> struct QfMfma<float> {
   static __device__ __host__ __forceinline__ int feat(int q, int t) { return 4 * q + t; }
 };
 
-template <typename T, int DT>  // DT = ceil(D / 16) feature blocks
+// KG > 0: the fused mixture E-step -- all Bo = K <= 4 KG components of a sample are in this block's chunk (Bi == 1, one
+// chunk), so the responsibilities are normalised right here (the K values of a sample sit on its four lane groups,
+// KG per lane) and p, NA and logZ leave the kernel: no (samples x K) round trip of the log-likelihoods, no second launch
+template <typename T, int DT, int KG = 0>  // DT = ceil(D / 16) feature blocks
 __global__ __launch_bounds__(256) void k_quadform_mfma(const T* __restrict__ X, int64_t S, int64_t Bo, int64_t Bi, int D,
                                                        const T* __restrict__ P, const T* __restrict__ b,
                                                        const T* __restrict__ c, T* __restrict__ out, int BC,
-                                                       int64_t tiles_per_block) {
+                                                       int64_t tiles_per_block, T* __restrict__ NA = nullptr,
+                                                       T* __restrict__ logZ = nullptr) {
   using M = QfMfma<T>;
   using acc_t = typename M::acc_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -574,6 +578,10 @@ __global__ __launch_bounds__(256) void k_quadform_mfma(const T* __restrict__ X, 
   const int64_t ntiles = (S + 15) / 16;
   const int64_t t_lo = (int64_t)blockIdx.x * tiles_per_block;
   const int64_t t_hi = (t_lo + tiles_per_block < ntiles) ? t_lo + tiles_per_block : ntiles;
+  [[maybe_unused]] T na_acc[KG > 0 ? KG : 1];  // running sum of p[s, 4g + q] over this lane's samples
+  [[maybe_unused]] T lz_acc = T(0);
+#pragma unroll
+  for (int gI = 0; gI < (KG > 0 ? KG : 1); ++gI) na_acc[gI] = T(0);
   for (int64_t tile = t_lo + wave; tile < t_hi; tile += 4) {
     const int64_t s = tile * 16 + j;
     const bool ok = s < S;
@@ -594,9 +602,10 @@ __global__ __launch_bounds__(256) void k_quadform_mfma(const T* __restrict__ X, 
     for (int bb = 0; bb < DT; ++bb)
 #pragma unroll
       for (int t = 0; t < 4; ++t) x[bb][t] = (M::feat(q, t) + 16 * bb < D) ? x[bb][t] : T(0);
+    [[maybe_unused]] T kv[KG > 0 ? KG : 1];
     // four components per round: lane group q keeps the value of component 4g + q, so that one store instruction
     // writes 16 samples x 4 adjacent components
-    for (int e0 = 0; e0 < nb; e0 += 4) {
+    for (int e0 = 0; e0 < (KG > 0 ? 4 * KG : nb); e0 += 4) {
       T keep = T(0);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -622,7 +631,70 @@ __global__ __launch_bounds__(256) void k_quadform_mfma(const T* __restrict__ X, 
         }
       }
       const int eq = e0 + q;
-      if (ok && eq < nb) out[(s * Bo + bo0 + eq) * Bi + bi] = keep;
+      if constexpr (KG > 0) {
+#pragma unroll
+        for (int gI = 0; gI < KG; ++gI)
+          if (4 * gI == e0) kv[gI] = (eq < nb) ? keep : -INFINITY;  // e0 steps through compile-time multiples of 4
+      } else {
+        if (ok && eq < nb) out[(s * Bo + bo0 + eq) * Bi + bi] = keep;
+      }
+    }
+    if constexpr (KG > 0) {
+      // softmax over the K = nb components of sample j: KG values on each of its four lanes (j, j+16, j+32, j+48)
+      T mx = kv[0];
+#pragma unroll
+      for (int gI = 1; gI < KG; ++gI) mx = kv[gI] > mx ? kv[gI] : mx;
+      T o = __shfl_xor(mx, 16, 64);
+      mx = o > mx ? o : mx;
+      o = __shfl_xor(mx, 32, 64);
+      mx = o > mx ? o : mx;
+      T sum = T(0);
+#pragma unroll
+      for (int gI = 0; gI < KG; ++gI) {
+        kv[gI] = exp(kv[gI] - mx);  // one exp per entry (components beyond K: exp(-inf) = 0)
+        sum += kv[gI];
+      }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const T inv = T(1) / sum;
+#pragma unroll
+      for (int gI = 0; gI < KG; ++gI) {
+        const T pv = kv[gI] * inv;
+        const int eq = 4 * gI + q;
+        if (ok && eq < nb) {
+          out[s * Bo + eq] = pv;
+          na_acc[gI] += pv;
+        }
+      }
+      if (ok && q == 0) lz_acc += mx + log(sum);
+    }
+  }
+  if constexpr (KG > 0) {
+    // block-level combine: over the 16 samples of a lane group (butterfly), then over the four waves through LDS (the
+    // parameter image is dead by now), then ONE atomic per component and block
+    __syncthreads();
+    T* red = reinterpret_cast<T*>(smem_raw);  // [wave][4 KG + 1]
+#pragma unroll
+    for (int gI = 0; gI < KG; ++gI) {
+      T v = na_acc[gI];
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (j == 0) red[wave * (4 * KG + 1) + 4 * gI + q] = v;
+    }
+    {
+      T v = lz_acc;
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) red[wave * (4 * KG + 1) + 4 * KG] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x <= 4 * KG) {
+      const int k = threadIdx.x;
+      const T tot = red[k] + red[(4 * KG + 1) + k] + red[2 * (4 * KG + 1) + k] + red[3 * (4 * KG + 1) + k];
+      if (k == 4 * KG)
+        atomicAdd(logZ, tot);
+      else if (k < nb)
+        atomicAdd(&NA[k], tot);
     }
   }
 }
@@ -685,10 +757,13 @@ __global__ __launch_bounds__(256) void k_estep_softmax(T* __restrict__ p, int64_
   }
 }
 
-// launch of the MFMA quadratic form; returns false when the shape is not served (caller falls back to k_quadform)
+// launch of the MFMA quadratic form; returns false when the shape is not served (caller falls back to k_quadform).
+// With NA / logZ given (mixture E-step, Bi == 1): the fused form when all Bo = K components fit one chunk and K <= 32;
+// *fused tells the caller whether p already holds the responsibilities.
 template <typename T>
 static bool quadform_mfma_launch(const T* X, int64_t S, int64_t Bo, int64_t Bi, int D, const T* P, const T* b,
-                                 const T* c, T* out, hipStream_t st) {
+                                 const T* c, T* out, hipStream_t st, T* NA = nullptr, T* logZ = nullptr,
+                                 bool* fused = nullptr) {
   if (D < 8 || D > 64 || S * Bi < 2048 || Bi > 65535) return false;
   const int DT = (D + 15) / 16;
   const size_t per = ((size_t)DT * DT * 256 + (size_t)DT * 256 + 1) * sizeof(T);
@@ -707,6 +782,19 @@ static bool quadform_mfma_launch(const T* X, int64_t S, int64_t Bo, int64_t Bi, 
   const int64_t gx = (ntiles + tpb - 1) / tpb;
   const dim3 g((unsigned)gx, (unsigned)Bi, (unsigned)nz), blk(256);
   const size_t smem = per * BC;
+  if (fused) *fused = false;
+  if (NA && logZ && Bi == 1 && nz == 1 && Bo <= 32 && !(g_vbmp_flags & 0x4000)) {  // 0x4000: two-kernel form (A/B, tests)
+    const int KG = Bo <= 4 ? 1 : Bo <= 8 ? 2 : Bo <= 16 ? 4 : 8;
+#define VBMP_QFF(DTV, KGV) \
+  hipLaunchKernelGGL((k_quadform_mfma<T, DTV, KGV>), g, blk, smem, st, X, S, Bo, Bi, D, P, b, c, out, BC, tpb, NA, logZ)
+#define VBMP_QFK(DTV) \
+  do { if (KG == 1) VBMP_QFF(DTV, 1); else if (KG == 2) VBMP_QFF(DTV, 2); else if (KG == 4) VBMP_QFF(DTV, 4); else VBMP_QFF(DTV, 8); } while (0)
+    if (DT == 1) VBMP_QFK(1); else if (DT == 2) VBMP_QFK(2); else if (DT == 3) VBMP_QFK(3); else VBMP_QFK(4);
+#undef VBMP_QFK
+#undef VBMP_QFF
+    if (fused) *fused = true;
+    return true;
+  }
 #define VBMP_QF(DTV) hipLaunchKernelGGL((k_quadform_mfma<T, DTV>), g, blk, smem, st, X, S, Bo, Bi, D, P, b, c, out, BC, tpb)
   if (DT == 1) VBMP_QF(1); else if (DT == 2) VBMP_QF(2); else if (DT == 3) VBMP_QF(3); else VBMP_QF(4);
 #undef VBMP_QF
@@ -744,7 +832,9 @@ static int estep_dispatch(const T* X, int64_t S, int K, int D, const T* P, const
   if (blocks > 256 * 8) blocks = 256 * 8;
   // D >= 8: log-likelihoods on the matrix cores into the p buffer, then the in-place softmax pass
   const size_t sm_smem = (size_t)512 * (K + 1) * sizeof(T);  // rows of a chunk + per-thread running sums
-  if (!(g_vbmp_flags & 0x100) && sm_smem <= 150 * 1024 && quadform_mfma_launch<T>(X, S, K, 1, D, P, b, c, p, st)) {
+  bool fused = false;
+  if (!(g_vbmp_flags & 0x100) && sm_smem <= 150 * 1024 && quadform_mfma_launch<T>(X, S, K, 1, D, P, b, c, p, st, NA, logZ, &fused)) {
+    if (fused) return hipGetLastError() == hipSuccess ? 0 : VBMP_ERR_LAUNCH;  // p, NA, logZ are complete
     if (sm_smem > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_estep_softmax<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)sm_smem) != hipSuccess)

@@ -242,7 +242,8 @@ def test_quadform_mfma_and_valu_forms(S, Bo, Bi, D, dtype, smoother_flags):
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 @pytest.mark.parametrize("S,K,D", [(4099, 4, 16), (2500, 33, 12), (3001, 6, 40), (2048, 2, 64),
-                                   (3000, 1, 4), (4099, 1, 16), (2049, 1, 2), (5000, 2, 4)])  # K = 1: single-component mixture
+                                   (3000, 1, 4), (4099, 1, 16), (2049, 1, 2), (5000, 2, 4),  # K = 1: single-component mixture
+                                   (4100, 16, 16), (5000, 20, 8), (6000, 7, 12), (3333, 32, 8), (2100, 5, 24)])  # fused softmax: KG = 4, 8, 2, 8, 2
 def test_mixture_estep_mfma_and_valu_forms(S, K, D, dtype, smoother_flags):
     from pyvbmp_amd import ops
     g = torch.Generator().manual_seed(S + K)
@@ -255,7 +256,7 @@ def test_mixture_estep_mfma_and_valu_forms(S, K, D, dtype, smoother_flags):
     lse = torch.logsumexp(l, -1)
     pref = torch.exp(l - lse[:, None])
     tol = 1e-11 if dtype == torch.float64 else 1e-4
-    for flag in (0, 0x100):
+    for flag in (0, 0x100, 0x4000):  # default (fused MFMA form where it applies) / VALU form / MFMA + separate softmax pass
         smoother_flags(flag)
         p, NA, logZ = ops.mixture_estep(X.to(DEV, dtype), P.to(DEV, dtype), b.to(DEV, dtype), c.to(DEV, dtype))
         assert_close(p, pref, tol, what=f"p flag={flag}")
