@@ -4,45 +4,26 @@ linear-Gaussian transforms (surface of the reference's dists/MultivariateNormal_
 Attributes mu / Sigma / invSigmamu / invSigma / logdetinvSigma are plain tensors that callers read,
 index-assign and reset to None, exactly as with the reference.  Conversions run K1 (one launch gives
 the inverse AND the logdet, which is cached in `logdetinvSigma` so that Res() does not factor again).
-"""
-import math
-
-import torch
-
+Shared arithmetic (moments, raw_update, Elog_like): `_gaussian.GaussianNode`."""
 from .. import ops
+from ._gaussian import LOG2PI, GaussianNode
 
-_LOG2PI = math.log(2.0 * math.pi)
 
+class MultivariateNormal_vector_format(GaussianNode):
+    _event_axes = 2
 
-class MultivariateNormal_vector_format():
     def __init__(self, mu=None, Sigma=None, invSigmamu=None, invSigma=None, logdetinvSigma=None):
-        self.mu = mu
-        self.Sigma = Sigma
-        self.invSigmamu = invSigmamu
-        self.invSigma = invSigma
+        self.mu, self.Sigma, self.invSigmamu, self.invSigma = mu, Sigma, invSigmamu, invSigma
         self.logdetinvSigma = logdetinvSigma
-        ref = mu if mu is not None else invSigmamu
-        if ref is None:
-            print('mu and invSigmamu are both None: cannont initialize MultivariateNormal')
-            return None
-        self.dim = ref.shape[-2]
-        self.event_shape = tuple(ref.shape[-2:])
-        self.batch_shape = tuple(ref.shape[:-2])
-        self.batch_dim = len(self.batch_shape)
-        self.event_dim = len(self.event_shape)
-        self.device, self.dtype = ref.device, ref.dtype
+        self._adopt_shapes(mu if mu is not None else invSigmamu)
 
     @property
     def shape(self):
         return self.batch_shape + self.event_shape
 
     def to_event(self, n):
-        if n == 0:
-            return self
-        self.event_dim = self.event_dim + n
-        self.batch_dim = self.batch_dim - n
-        self.event_shape = self.batch_shape[-n:] + self.event_shape
-        self.batch_shape = self.batch_shape[:-n]
+        if n != 0:
+            self._shift_event(n)
         return self
 
     def unsqueeze(self, dim):
@@ -50,24 +31,25 @@ class MultivariateNormal_vector_format():
         parts = [None if t is None else t.unsqueeze(dim) for t in (self.mu, self.Sigma, self.invSigmamu, self.invSigma)]
         return MultivariateNormal_vector_format(*parts).to_event(self.event_dim - 2)
 
-    def _reset_moments(self):
-        self.Sigma = None
-        self.mu = None
-        self.logdetinvSigma = None
-
-    def combiner(self, other):
-        self.invSigma = self.EinvSigma() + other.EinvSigma()
-        self.invSigmamu = self.EinvSigmamu() + other.EinvSigmamu()
-        self._reset_moments()
-
-    def nat_combiner(self, invSigma, invSigmamu):
+    # ---------------------------------------------------------------- combining messages (natural parameters add)
+    def _absorb(self, invSigma, invSigmamu):
         self.invSigma = self.EinvSigma() + invSigma
         self.invSigmamu = self.EinvSigmamu() + invSigmamu
-        self._reset_moments()
+        self.Sigma = self.mu = self.logdetinvSigma = None
 
-    def _factor_precision(self):
-        """Sigma and log det invSigma from ONE factorisation of invSigma."""
-        self.Sigma, ld = ops.spd_inv_logdet(self.invSigma)
+    def combiner(self, other):
+        self._absorb(other.EinvSigma(), other.EinvSigmamu())
+
+    def nat_combiner(self, invSigma, invSigmamu):
+        self._absorb(invSigma, invSigmamu)
+
+    # ---------------------------------------------------------------- conversions: one factorisation serves two attributes
+    def _factor(self, of_precision):
+        inv, ld = ops.spd_inv_logdet(self.invSigma if of_precision else self.Sigma)
+        if of_precision:
+            self.Sigma = inv
+        else:
+            self.invSigma, ld = inv, -ld
         if self.logdetinvSigma is None:
             self.logdetinvSigma = ld
 
@@ -78,14 +60,12 @@ class MultivariateNormal_vector_format():
 
     def ESigma(self):
         if self.Sigma is None:
-            self._factor_precision()
+            self._factor(True)
         return self.Sigma
 
     def EinvSigma(self):
         if self.invSigma is None:
-            self.invSigma, ld = ops.spd_inv_logdet(self.Sigma)
-            if self.logdetinvSigma is None:
-                self.logdetinvSigma = -ld
+            self._factor(False)
         return self.invSigma
 
     def EinvSigmamu(self):
@@ -95,49 +75,16 @@ class MultivariateNormal_vector_format():
 
     def ElogdetinvSigma(self):
         if self.logdetinvSigma is None:
-            if self.invSigma is None:
-                self.EinvSigma()
-            else:
-                self._factor_precision()
+            self._factor(self.invSigma is not None)
         return self.logdetinvSigma
-
-    def EX(self):
-        return self.mean()
-
-    def EXXT(self):
-        m = self.mean()
-        return self.ESigma() + m @ m.transpose(-2, -1)
 
     def EXTX(self):
         m = self.mean()
         return self.ESigma().sum((-1, -2)) + (m.transpose(-2, -1) @ m).squeeze(-1).squeeze(-1)
 
     def Res(self):
-        return -0.5 * (self.mean() * self.EinvSigmamu()).sum((-1, -2)) + 0.5 * self.ElogdetinvSigma() \
-            - 0.5 * self.dim * _LOG2PI
+        return -0.5 * (self.mean() * self.EinvSigmamu()).sum((-1, -2)) + 0.5 * self.ElogdetinvSigma() - 0.5 * self.dim * LOG2PI
 
     def ss_update(self, SExx, SEx, n, lr=1.0):
-        # the moment form (the reference defines ss_update twice; this later definition, :121-126, wins)
-        n = n.unsqueeze(-1).unsqueeze(-1)
-        self.mu = SEx / n
-        self.Sigma = SExx / n - self.mu @ self.mu.transpose(-2, -1)
-        self.invSigma = None
-        self.invSigmamu = None
-
-    def raw_update(self, X, p=None, lr=1.0):
-        nsd = X.ndim - self.event_dim - self.batch_dim
-        n, SEx, SExx = ops.weighted_moments(X.squeeze(-1), p, nsd, self.batch_shape)
-        self.ss_update(SExx, SEx.unsqueeze(-1), n, lr)
-
-    def Elog_like(self, X):
-        P = self.EinvSigma()
-        d = (X - self.mu).squeeze(-1)
-        zero = torch.zeros(self.batch_shape + (self.dim,), device=X.device, dtype=X.dtype)
-        cst = 0.5 * self.ElogdetinvSigma() - 0.5 * self.dim * _LOG2PI
-        out = ops.quadform_loglike(d, P, zero, cst.expand(self.batch_shape))
-        for i in range(self.event_dim - 2):
-            out = out.sum(-1)
-        return out
-
-    def KLqprior(self):
-        return torch.tensor(0.0, device=self.device, dtype=self.dtype)
+        # the moment form (the reference defines ss_update twice; its later definition, :121-126, wins)
+        self._set_moments_from_statistics(SExx, SEx, n)
