@@ -5,16 +5,28 @@
 #include <cstdio>
 using f32x16 = float __attribute__((ext_vector_type(16)));
 
-template <int MODE>  // bit0: MFMA waves work, bit1: VALU waves work, bit2: VALU waves use DPP fmac
+using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
+
+template <int MODE>  // bit0: MFMA waves work, bit1: VALU waves work, bit2: VALU waves use DPP fmac, bit3: bf16 MFMA instead of f32
 __global__ __launch_bounds__(512) void k(float* out, int iters) {
   const int wave = threadIdx.x >> 6;
   float x = threadIdx.x * 1e-3f, y = 1.0001f;
   if (wave < 4) {
     if (MODE & 1) {
       f32x16 acc = {0};
-      for (int i = 0; i < iters; ++i) {
+      if (MODE & 8) {
+        bf16x8 a8, b8;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc, 0, 0, 0);
+        for (int u = 0; u < 8; ++u) { a8[u] = (__bf16)(x + u); b8[u] = (__bf16)(y + u); }
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+          for (int u = 0; u < 32; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc, 0, 0, 0);  // 32 x 32 cycles = the time of 16 f32 MFMAs
+        }
+      } else {
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+          for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc, 0, 0, 0);
+        }
       }
       out[blockIdx.x * 512 + threadIdx.x] = acc[0] + acc[5];
     }
@@ -68,5 +80,8 @@ int main() {
   printf("both (fmac)               : %.3f ms\n", run<3>(out, it));
   printf("VALU waves only (dpp fmac): %.3f ms\n", run<6>(out, it));
   printf("both (dpp fmac)           : %.3f ms\n", run<7>(out, it));
+  printf("bf16 MFMA waves only      : %.3f ms\n", run<9>(out, it));
+  printf("bf16 MFMA + VALU (fmac)   : %.3f ms\n", run<11>(out, it));
+  printf("bf16 MFMA + VALU (dpp)    : %.3f ms\n", run<15>(out, it));
   return 0;
 }
