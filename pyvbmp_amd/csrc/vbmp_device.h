@@ -318,6 +318,29 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
+// LDS image offset (in elements) of the 16-byte chunk c = lane + 64 i of a full tile, split into a per-lane base and a
+// compile-time constant per i -- written as (lane + 64 i) / cpr ... the compiler keeps one address register PER i (16 of
+// them for a 32 x 32 fp32 tile, all loop invariants, all spilled).  A wave instruction covers RPI = 64 / cpr rows.
+template <typename T, int Dp, int G>
+struct TileChunk {
+  using TL = Tile<T, Dp, G>;
+  static constexpr int cpr = Dp / TL::V > 0 ? Dp / TL::V : 1;  // chunks per row
+  static constexpr int RPI = 64 / cpr > 0 ? 64 / cpr : 1;      // rows per wave instruction
+  static __device__ __forceinline__ int base(int lane) {
+    const int r0 = lane / cpr, cc = lane % cpr;
+    if constexpr (Dp % RPI == 0)
+      return r0 * TL::RS + cc * TL::V;
+    else  // RPI is a multiple of Dp: an instruction covers RPI / Dp whole matrices
+      return (r0 / Dp) * TL::MS + (r0 % Dp) * TL::RS + cc * TL::V;
+  }
+  static constexpr int off(int i) {
+    if constexpr (Dp % RPI == 0)
+      return ((RPI * i) / Dp) * TL::MS + ((RPI * i) % Dp) * TL::RS;
+    else
+      return (RPI / Dp) * i * TL::MS;
+  }
+};
+
 // global (linear, coalesced) -> per-wave LDS image [m][row][col] with padded strides.
 // g points at the first matrix of the tile; matrices are `gstride` elements apart; `nm` valid.
 // FULL: D == Dp, the tile is contiguous and 16-byte aligned (checked on the host) -> all index
@@ -335,9 +358,10 @@ __device__ __forceinline__ void tile_g2lds(const T* __restrict__ g, int64_t gstr
     const typename TL::vec_t* gv = reinterpret_cast<const typename TL::vec_t*>(g);
     // branch-free: a partial last tile re-reads its final chunk and fills LDS slots nobody consumes
     typename TL::vec_t v[NIT];
+    const typename TL::vec_t* gl = gv + lane;  // one per-lane pointer, constant offsets 64 i from it
     if (nm == TL::MPW) {  // wave-uniform: constant offsets from one base address; streamed once -> nt
 #pragma unroll
-      for (int i = 0; i < NIT; ++i) v[i] = NT ? __builtin_nontemporal_load(&gv[lane + 64 * i]) : gv[lane + 64 * i];
+      for (int i = 0; i < NIT; ++i) v[i] = NT ? __builtin_nontemporal_load(&gl[64 * i]) : gl[64 * i];
     } else {
 #pragma unroll
       for (int i = 0; i < NIT; ++i) {
@@ -345,13 +369,11 @@ __device__ __forceinline__ void tile_g2lds(const T* __restrict__ g, int64_t gstr
         v[i] = gv[c < nchunk ? c : nchunk - 1];
       }
     }
+    using TC = TileChunk<T, Dp, G>;
+    T* lb = lds + TC::base(lane);
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int c = lane + 64 * i;
-      const int row_all = c / cpr, cc = c % cpr;
-      const int m = row_all / Dp, row = row_all % Dp;
-      if (c < TL::MPW * Dp * Dp / TL::V)
-        *reinterpret_cast<typename TL::vec_t*>(&lds[m * TL::MS + row * TL::RS + cc * TL::V]) = v[i];
+      if (lane + 64 * i < TL::MPW * Dp * Dp / TL::V) *reinterpret_cast<typename TL::vec_t*>(lb + TC::off(i)) = v[i];
     }
   } else {
     // generic D: same shape as the FULL path -- a compile-time trip count (that of the padded tile, in groups of at
@@ -428,20 +450,19 @@ __device__ __forceinline__ void tile_lds2g(T* __restrict__ g, int nm, int Drt, c
     const int nchunk = nm * (Dp * Dp / TL::V);
     typename TL::vec_t* gv = reinterpret_cast<typename TL::vec_t*>(g);
     typename TL::vec_t v[NIT];
+    using TC = TileChunk<T, Dp, G>;
+    const T* lb = lds + TC::base(lane);
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int c = lane + 64 * i;
-      const int row_all = c / cpr, cc = c % cpr;
-      const int m = row_all / Dp, row = row_all % Dp;
-      if (c < TL::MPW * Dp * Dp / TL::V)
-        v[i] = *reinterpret_cast<const typename TL::vec_t*>(&lds[m * TL::MS + row * TL::RS + cc * TL::V]);
+      if (lane + 64 * i < TL::MPW * Dp * Dp / TL::V) v[i] = *reinterpret_cast<const typename TL::vec_t*>(lb + TC::off(i));
     }
+    typename TL::vec_t* gl = gv + lane;
     if (nm == TL::MPW) {  // wave-uniform: unpredicated stores, constant offsets; written once -> nt
 #pragma unroll
       for (int i = 0; i < NIT; ++i)
         if (lane + 64 * i < TL::MPW * Dp * Dp / TL::V) {
-          if (NT) __builtin_nontemporal_store(v[i], &gv[lane + 64 * i]);
-          else gv[lane + 64 * i] = v[i];
+          if (NT) __builtin_nontemporal_store(v[i], &gl[64 * i]);
+          else gl[64 * i] = v[i];
         }
     } else {
 #pragma unroll
