@@ -92,3 +92,31 @@ def test_bench_under_torch_distributed_run():
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["scaling"] == "weak" and out["steps"] == 3
     assert out["metric"].startswith("conjugate updates/sec") and out["unit"] == "updates/s"
     assert out["value"] > 0 and 0 < out["roofline"]["frac"] < 1.2
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("workload,extra", [("niw", ["--batch", "100000"]), ("mnw_fwd", ["--batch", "8192"]), ("mnw_bwd", ["--batch", "8192"]),
+                                            ("lds", ["--batch", "256", "--T", "100"]), ("dmbd", ["--batch", "4"])])
+def test_bench_workloads_emit_the_contract_line(workload, extra):
+    """every workload of bench.py on one GPU (small sizes): ONE JSON line with the contract's keys, a roofline object whose
+    numbers are consistent with each other, and a cpu_baseline (or an explicit null for dmbd)"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "3", "--warmup", "1"] + extra
+    r = subprocess.run(cmd, env=_plain_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["warmup"] == 1 and out["data"] == "synthetic" and out["vs_baseline"] is None
+    assert "workload" in out["config"] and "model" not in out["config"]
+    ro = out["roofline"]
+    assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["peak"] == 8000.0
+    assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-12 and ro["kernel_ms"] > 0
+    assert ro["kernel_ms"] <= out["ms_per_step"] * 1.05  # the dominant kernel cannot take longer than the step it is part of
+    if workload == "dmbd":
+        assert out["cpu_baseline"] is None and out["config"]["elbo_finite"] is True
+    else:
+        cb = out["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == out["unit"] and cb["sample"]
