@@ -33,6 +33,8 @@ def test_checker_sees_a_hazard_and_its_fix():
             (["v_mov_b32_e32 v5, v9", dpp], 0),                                  # another register
             (["v_fma_f64 v[2:3], v[4:5], v[6:7], v[8:9]", "v_mov_b64_dpp v[10:11], v[2:3] row_newbcast:0 row_mask:0xf bank_mask:0xf"], 1),
             (["global_load_dword v2, v[4:5], off", dpp], 0),                     # not a VALU write (tracked by s_waitcnt)
+            (["v_cmpx_lt_f32_e32 v4, v5", "s_nop 1", "s_nop 0", dpp], 1),          # VALU write of EXEC: 3 wait states, needs 5
+            (["v_cmpx_lt_f32_e32 v4, v5", "s_nop 4", dpp], 0),
             # the writer sits in front of a branch whose target is the DPP instruction
             (["v_mov_b32_e32 v2, v9", "s_cbranch_scc1 2 <k+0x10>", "s_nop 1", "s_nop 1", dpp], 1),
     ):

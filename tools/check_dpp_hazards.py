@@ -2,9 +2,10 @@
 """Static check of the built gfx950 code objects for the DPP read-after-write hazard.
 
 The kernels issue their DPP instructions (v_fmac_*_dpp / v_mov_*_dpp with row_newbcast / quad_perm) from inline asm, and
-hipcc pads nothing around or inside inline asm.  gfx9 rule: a VGPR written by a VALU instruction may be read through a
-DPP operand (src0 of a *_dpp instruction) only after 2 wait states; every instruction issued in between is one wait
-state, `s_nop N` is N + 1.  Most of our DPP groups sit far away from the writer of their source rows, so their `s_nop`
+hipcc pads nothing around or inside inline asm.  gfx9 rules: (1) a VGPR written by a VALU instruction may be read through
+a DPP operand (src0 of a *_dpp instruction) only after 2 wait states; (2) a VALU instruction that writes EXEC (v_cmpx_*,
+v_* with an exec destination) must be 5 wait states ahead of any DPP instruction.  Every instruction issued in between is
+one wait state, `s_nop N` is N + 1.  Most of our DPP groups sit far away from the writer of their source rows, so their `s_nop`
 pads are dead weight (they were ~17 % of the instructions of the MatrixNormalWishart message kernel) -- but whether a
 particular pad can go depends on what the register allocator places in front of the asm block (a copy, an accumulator
 read), which no source-level argument can promise.  This script decides it on the final ISA instead: it disassembles the
@@ -25,7 +26,8 @@ import tempfile
 
 LLVM = "/opt/rocm/lib/llvm/bin"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-WAIT_STATES = 2
+WAIT_STATES = 2       # VALU write of a VGPR -> DPP read of it
+WAIT_STATES_EXEC = 5  # VALU write of EXEC -> any DPP instruction
 
 _INS = re.compile(r"^\s+([a-z_0-9]+)\s*(.*?)\s*//\s*([0-9A-F]+):")
 _FUNC = re.compile(r"^([0-9a-f]+) <([^>]+)>:")
@@ -62,7 +64,7 @@ def split_operands(text):
 
 
 class Ins:
-    __slots__ = ("addr", "op", "text", "ops", "wait", "vwrite", "dppsrc", "target", "ends")
+    __slots__ = ("addr", "op", "text", "ops", "wait", "vwrite", "dppsrc", "target", "ends", "wexec")
 
     def __init__(self, addr, op, text, func_base):
         self.addr, self.op, self.text = addr, op, text
@@ -76,6 +78,7 @@ class Ins:
             self.vwrite = vregs(self.ops[0])
             if op.startswith("v_swap"):
                 self.vwrite = self.vwrite | vregs(self.ops[1])
+        self.wexec = op.startswith("v_cmpx") or (op.startswith("v_") and bool(self.ops) and self.ops[0].strip().startswith("exec"))
         self.dppsrc = frozenset()
         if "_dpp" in op or " row_" in text or " quad_perm" in text:
             # vdst, src0 (the DPP operand), ...
@@ -130,27 +133,29 @@ def check_function(ins):
             preds.setdefault(index[i.target], []).append(k)
     bad = []
 
-    def walk(k, budget, src, reader, seen):
+    def walk(k, budget, hit, reader, seen):
         """instructions that can execute right before position k, while fewer than `budget` wait states have passed"""
         if budget <= 0 or k < 0:
             return
         for j in preds.get(k, ()):  # jumped here: the branch itself was the previous instruction
             if (j, budget) not in seen:
                 seen.add((j, budget))
-                visit(j, budget, src, reader, seen)
+                visit(j, budget, hit, reader, seen)
         if k > 0 and not ins[k - 1].ends:
-            visit(k - 1, budget, src, reader, seen)
+            visit(k - 1, budget, hit, reader, seen)
 
-    def visit(j, budget, src, reader, seen):
+    def visit(j, budget, hit, reader, seen):
         i = ins[j]
-        if i.vwrite & src:
+        if hit(i):
             bad.append((reader, j))
             return
-        walk(j, budget - i.wait, src, reader, seen)
+        walk(j, budget - i.wait, hit, reader, seen)
 
     for k, i in enumerate(ins):
         if i.dppsrc:
-            walk(k, WAIT_STATES, i.dppsrc, k, set())
+            src = i.dppsrc
+            walk(k, WAIT_STATES, lambda w: bool(w.vwrite & src), k, set())
+            walk(k, WAIT_STATES_EXEC, lambda w: w.wexec, k, set())
     return bad
 
 
@@ -162,8 +167,8 @@ def check_object(obj):
         nnop += sum(1 for i in ins if i.op == "s_nop")
         for reader, writer in check_function(ins):
             r, w = ins[reader], ins[writer]
-            report.append(f"{os.path.basename(obj)}: {name}: {w.op} {w.text} @{w.addr:x} writes the DPP source of "
-                          f"{r.op} {r.text} @{r.addr:x} with fewer than {WAIT_STATES} wait states in between")
+            what = "writes EXEC fewer than 5 wait states ahead of" if w.wexec else "writes the DPP source, fewer than 2 wait states ahead, of"
+            report.append(f"{os.path.basename(obj)}: {name}: {w.op} {w.text} @{w.addr:x} {what} {r.op} {r.text} @{r.addr:x}")
     return report, ndpp, nnop
 
 
