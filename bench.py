@@ -436,6 +436,7 @@ def main():
     ap.add_argument("--oversubscribe", action="store_true", help="rehearsal on a box with fewer GPUs than ranks: ranks share "
                     "the cards round-robin (use with --backend gloo; RCCL wants one GPU per rank); never for reported numbers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strong", action="store_true", dest="no_strong", help="N > 1: skip the extra strong-scaling pass")
     args = ap.parse_args()
     args.batch_set, args.dim_set, args.dtype_set = args.batch, args.dim, args.dtype
     if args.batch is None:
@@ -520,6 +521,26 @@ def main():
         dist.all_reduce(u, op=dist.ReduceOp.SUM)
         units_total = float(u[0])
 
+    # N > 1, headline workload, weak scaling: the same K steps once more with the batch as the TOTAL (1e6 over all GPUs),
+    # AFTER and outside the timed region above, so that one driver run yields the weak AND the strong scaling point
+    strong = None
+    if dist is not None and args.workload == "niw" and args.scaling == "weak" and not args.no_strong:
+        del wl.SExx, wl.SEx, wl.N, wl.q
+        torch.cuda.empty_cache()
+        ws = NiwWorkload(args)
+        ws.setup(device, rank, world, "strong")
+        for _ in range(args.warmup):
+            ws.step()
+        barrier()
+        t0s = time.perf_counter()
+        for _ in range(args.steps):
+            ws.step()
+        barrier()
+        ts = torch.tensor([time.perf_counter() - t0s], dtype=torch.float64, device=device)
+        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        strong = {"scaling": "strong", "batch_total": args.batch, "value": args.batch * args.steps / float(ts[0]),
+                  "unit": ws.unit, "ms_per_step": float(ts[0]) / args.steps * 1e3, "steps": args.steps}
+
     if rank == 0:
         achieved = wl.bytes_per_launch / (kernel_ms * 1e-3) / 1e9  # GB/s of algorithmic bytes, one launch of rank 0's share
         traffic, traffic_source = None, None
@@ -554,6 +575,8 @@ def main():
             "config": wl.config(world, args.scaling),
             "roofline": roof,
         }
+        if strong is not None:
+            out["strong_scaling"] = strong
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -92,6 +92,8 @@ def test_bench_under_torch_distributed_run():
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["scaling"] == "weak" and out["steps"] == 3
     assert out["metric"].startswith("conjugate updates/sec") and out["unit"] == "updates/s"
     assert out["value"] > 0 and 0 < out["roofline"]["frac"] < 1.2
+    st = out["strong_scaling"]  # the same run also reports the strong-scaling point (batch = total)
+    assert st["scaling"] == "strong" and st["batch_total"] == 200000 and st["value"] > 0 and st["steps"] == 3
 
 
 @pytest.mark.timeout(600)
