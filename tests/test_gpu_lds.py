@@ -316,3 +316,34 @@ def test_lds_single_steps_meet_the_north_star_tolerance(T, dtype, tol):
         assert_close(getattr(m.px, f), sm[f], tol, what=f"{f} T={T}")
     st = olds.latent_stats(sm, yo, uo, ro, (6,), 1, 1, (), 0)
     assert_close(m.logZ, st["logZ"], tol, what="logZ")
+
+
+@pytest.mark.parametrize("mode", ["exact", "default"])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("h,T,S", [(6, 300, 13), (3, 120, 5), (8, 90, 4), (6, 3, 4), (6, 40, 9)])
+def test_lds_fixed_point_shortcut_against_the_full_recursion(h, T, S, dtype, mode, smoother_flags):
+    """K9 stops its matrix recursions once they have converged (time-independent likelihood precision) and runs only the
+    mean recursion from there.  Flag 0x800 stops only at a BITWISE repeat: every output must then be bit for bit what the
+    full recursion (flag 0x8000) produces.  The default also stops when the precision has moved by <= 4 ulp for 8 steps in
+    a row (a last-bit limit cycle of the full recursion): outputs agree to rounding (1e-13 fp64 / 2e-6 fp32, normwise)."""
+    from pyvbmp_amd.models import LinearDynamicalSystems
+    g = torch.Generator().manual_seed(h * 1000 + T)
+    y = lorenz(T, S, g).to(dtype).to(DEV)
+    outs = []
+    for flag in (0x8000, 0x800 if mode == "exact" else 0):
+        smoother_flags(flag)
+        torch.manual_seed(3)
+        m = LinearDynamicalSystems((6,), h, latent_noise='shared', device=DEV, dtype=dtype)
+        m.update_latents(*m.reshape_inputs(y))
+        outs.append({f: getattr(m.px, f).clone() for f in ("mu", "Sigma", "invSigma", "invSigmamu")} |
+                    {f: getattr(m, f).clone() for f in ("logZ", "SE_x_x", "SE_x_xpu", "SE_xpu_xpu", "SE_x0_x0", "SE_x0")})
+    full, short = outs
+    tol = 1e-13 if dtype == torch.float64 else 2e-6
+    for k in full:
+        if mode == "exact":
+            assert torch.equal(full[k], short[k]), f"{k}: max abs diff {float((full[k] - short[k]).abs().max()):.3e}"
+        else:
+            assert_close(short[k], full[k], tol, what=k)
+    if mode == "default" and T >= 90:  # the shortcut was taken: the smoothed covariance is constant in the middle
+        mid = short["Sigma"][T // 2 - 2:T // 2 + 2]
+        assert torch.equal(mid[0], mid[1]) and torch.equal(mid[1], mid[2])
