@@ -55,7 +55,7 @@ def _sig_wmom(T):
 def lds_args_struct(cT):
     """ctypes mirror of vbmp_lds_args_{f64,f32} (include/vbmp_hip.h)."""
     P = _c_ptr
-    fields = [("T", _c_i64), ("S", _c_i64), ("NB", _c_i64), ("H", _c_int)]
+    fields = [("T", _c_i64), ("S", _c_i64), ("NB", _c_i64), ("H", _c_int), ("flags", _c_int)]
     fields += [(n, P) for n in ("invQ", "ATQA_xx", "QA_xp_x", "A_Elogdet", "x0_P", "x0_eta", "x0_res")]
     for n, pre in (("like_P", "lP"), ("like_eta", "le"), ("like_res", "lr"), ("cu1", "c1"), ("cu2", "c2"), ("cu3", "c3")):
         fields += [(n, P), (pre + "_t", _c_i64), (pre + "_s", _c_i64), (pre + "_b", _c_i64)]
@@ -65,6 +65,7 @@ def lds_args_struct(cT):
 
 
 LDS_ARGS = {"f64": lds_args_struct(ctypes.c_double), "f32": lds_args_struct(ctypes.c_float)}
+LDS_CROSS_WORK = 1     # vbmp_lds_args.flags: only slot T-1 of Sigma_t_tp1 is wanted
 LDS_MAX_H = 8          # register-resident smoother forms
 LDS_MAX_H_BLOCK = 64   # block-per-series form (LDS-resident matrices); also bounded by lds_block_fits()
 

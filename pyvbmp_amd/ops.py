@@ -299,8 +299,9 @@ def _norm3(X, T, sample_shape, bo_shape, inner):
 
 
 def lds_smoother(T, sample_shape, bo_shape, H, invQ, ATQA_xx, QA_xp_x, A_Elogdet, x0_P, x0_eta, x0_res,
-                 like_P, like_eta, like_res, cu1, cu2, cu3):
+                 like_P, like_eta, like_res, cu1, cu2, cu3, dense_cross=True):
     """K9: one persistent launch of the information filter + smoother.
+    dense_cross=False: only slot T-1 of the returned Sigma_t_tp1 is meaningful (the rest is the sweeps' work buffer).
     System / prior parameters: bo_shape + (...).  Per-step operands: broadcastable to (T,)+sample+bo+(...).
     Returns dict of dense outputs shaped (T,)+sample+bo+(...) (and sample+bo+(...) for the x0 terms)."""
     dev = L.require_device(invQ, like_eta)
@@ -334,6 +335,7 @@ def lds_smoother(T, sample_shape, bo_shape, H, invQ, ATQA_xx, QA_xp_x, A_Elogdet
            "sum_xpx": torch.empty(lead[1:] + (H, H), dtype=dt, device=dev)}
     a = L.LDS_ARGS[suf]()
     a.T, a.S, a.NB, a.H = T, S, NB, H
+    a.flags = 0 if dense_cross else L.LDS_CROSS_WORK
     for name, t in zip(("invQ", "ATQA_xx", "QA_xp_x", "A_Elogdet", "x0_P", "x0_eta", "x0_res"), keep):
         setattr(a, name, t.data_ptr())
     for (name, pre), (t, st) in zip((("like_P", "lP"), ("like_eta", "le"), ("like_res", "lr"), ("cu1", "c1"),

@@ -347,3 +347,38 @@ def test_lds_fixed_point_shortcut_against_the_full_recursion(h, T, S, dtype, mod
     if mode == "default" and T >= 90:  # the shortcut was taken: the smoothed covariance is constant in the middle
         mid = short["Sigma"][T // 2 - 2:T // 2 + 2]
         assert torch.equal(mid[0], mid[1]) and torch.equal(mid[1], mid[2])
+
+
+@pytest.mark.parametrize("form", ["rows", "lanes"])
+@pytest.mark.parametrize("T", [3, 60, 400])
+def test_lds_cross_covariances_dense_and_work_buffer_modes(T, form, smoother_form):
+    """forward_backward_loop returns every Sigma_t_tp1[t] like the reference (:361-381); update_latents asks the kernel only for
+    slot T-1 and the time sums (vbmp_lds_args.flags & VBMP_LDS_CROSS_WORK).  Dense mode: all slots against the oracle; work
+    buffer mode: slot T-1 and every other output identical to the dense run."""
+    from oracle import lds as olds
+    from oracle import mnw as omnw
+    from oracle import niw as oniw
+    from pyvbmp_amd.models import LinearDynamicalSystems
+    smoother_form(form)
+    h, S = 6, 9
+    y = lorenz(T, S, torch.Generator().manual_seed(T))
+    m = LinearDynamicalSystems((6,), h, latent_noise='shared', device=DEV, dtype=torch.float64)
+    x0 = oniw.niw_new((h,), (), mu_init=m.x0.mu.cpu())
+    A = omnw.mnw_new((h, h + 1), (), mu_init=m.A.mu.cpu())
+    obs = omnw.mnw_new((6, h + 1), (), mu_init=m.obs_model.mu.cpu())
+    yy, uu, rr = m.reshape_inputs(y.to(DEV))
+    m.px = None
+    from pyvbmp_amd.dists import MultivariateNormal_vector_format
+    m.px = MultivariateNormal_vector_format(mu=torch.zeros(tuple(yy.shape[:-2]) + (h, 1), device=DEV, dtype=torch.float64))
+    cross, S00, m0, logZ, _ = m.forward_backward_loop(yy, uu, rr)
+    dense = {f: getattr(m.px, f).clone() for f in ("mu", "Sigma", "invSigma", "invSigmamu")}
+    sums = tuple(t.clone() for t in m._time_sums)
+    yo, uo, ro = olds.reshape_inputs(y, None, None, (6,), 1, 1)
+    sm = olds.smoother(olds.latent_parms(A, h), x0, h, yo, uo, ro, obs, 0)
+    assert_close(cross, sm["Sigma_t_tp1"], 1e-10, what="Sigma_t_tp1")
+    cross2, S002, m02, logZ2, _ = m.forward_backward_loop(yy, uu, rr, dense_cross=False)
+    assert torch.equal(cross2[-1], cross[-1]) and torch.equal(logZ2, logZ) and torch.equal(S002, S00) and torch.equal(m02, m0)
+    for f, v in dense.items():
+        assert torch.equal(getattr(m.px, f), v), f
+    for a, b in zip(m._time_sums, sums):
+        assert torch.equal(a, b)
