@@ -40,11 +40,18 @@ def _k12_pays(rows, k, n):
     return rows >= 16384 and k * n <= 256
 
 
-def shared_matvec(G, Y):
+def shared_matvec(G, Y, bias=None):
     """G @ Y for a stack of SHARED small matrices G (batch + (n, k), no sample axes) and per-sample vectors
     Y (sample + (1,)*len(batch) + (k, 1)): one (samples, k) x (k, batch*n) library GEMM instead of the
     samples*batch tiny matrix-vector products a broadcasting `@` is lowered to (600 000 of them, 2 ms, for the role
     emissions of the flocking DMBD).  Anything that does not have this shape goes to `@` unchanged."""
+    if bias is not None:
+        # bias: (n,) added to every product -- fused into K12 where that kernel runs, a broadcast add elsewhere
+        if G.dim() == 2 and Y.dim() > 2 and Y.shape[-1] == 1 and Y.is_cuda and G.shape[-1] > 0 and Y.numel() > 0 \
+                and _k12_pays(Y.numel() // G.shape[-1], G.shape[-1], G.shape[-2]):
+            from . import ops
+            return ops.rows_affine(Y.reshape(-1, G.shape[-1]), G, bias).reshape(tuple(Y.shape[:-2]) + (G.shape[-2], 1))
+        return shared_matvec(G, Y) + bias.unsqueeze(-1)
     nb = G.dim() - 2
     if G.shape[-1] == 0 or Y.numel() == 0:
         return G @ Y  # empty contraction (e.g. no regressors: regression_dim = -1 in DynamicMarkovBlanketDiscovery)

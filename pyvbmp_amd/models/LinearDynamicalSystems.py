@@ -312,7 +312,12 @@ class LinearDynamicalSystems():
 
         invSigma_t_t = self.BTRB_xp_xp
         Rc = self._compact(R, 2)  # the regressor is usually the constant bias column: keep it unexpanded
-        if self.BTR_xp_y.ndim == 2:
+        # a regressor that is the same for every (t, series) -- the usual bias column -- contributes constants: they ride along
+        # in the two streaming kernels below instead of costing three more passes over (T, series, obs)
+        const_r = Rc.numel() > 0 and all(s == 1 for s in Rc.shape[:-2]) and self.BTR_xp_y.ndim == 2
+        if const_r:
+            invSigmamu_t = shared_matvec(self.BTR_xp_y, Y, bias=-(self.BTRB_xp_r @ Rc).reshape(h))
+        elif self.BTR_xp_y.ndim == 2:
             # one shared (h x obs) map applied to T*S observations: K12 streams the rows once when there are many (a
             # broadcast `@` is a batched (h x obs)@(obs x 1) product per (t, series), and even the tall-skinny row-major
             # GEMM Y2 @ M^T reaches a tenth of the memory bandwidth at 4e6 x 6 by 6 x 6)
@@ -323,7 +328,9 @@ class LinearDynamicalSystems():
         cst = 0.5 * self.obs_model.ElogdetinvSigma() - 0.5 * self.obs_dim * _LOG2PI
         lin = (_T(self.BTR_r_y) @ Rc).squeeze(-1)
         quad_r = -0.5 * (_T(Rc) @ self.BTRB_r_r @ Rc).squeeze(-1).squeeze(-1)
-        if lin.ndim == cst.ndim + 1 and tuple(lin.shape[:-1]) == tuple(cst.shape):
+        if const_r and cst.ndim == 0:
+            Residual = ops.quadform_loglike(Y.squeeze(-1), self.invR, lin.reshape(self.obs_dim), cst + quad_r.reshape(()))
+        elif lin.ndim == cst.ndim + 1 and tuple(lin.shape[:-1]) == tuple(cst.shape):
             Residual = ops.quadform_loglike(Y.squeeze(-1), self.invR, lin, cst) + quad_r
         else:
             zero = torch.zeros(tuple(cst.shape) + (self.obs_dim,), device=Y.device, dtype=Y.dtype)
