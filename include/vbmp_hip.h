@@ -132,9 +132,12 @@ int vbmp_weighted_moments_f32(const float* X, const float* p, int64_t S, int64_t
  * flags & VBMP_LDS_CROSS_WORK: the caller only wants slot T-1 of Sigma_t_tp1 (the x0 cross term, which is all that
  * update_latents reads next to sum_xpx, :178); the other slots are then a work buffer of the sweeps (still (T,S,H,H)) whose
  * final contents are unspecified, and the kernel may skip their stores.
+ * flags & VBMP_LDS_LOGZ_SUM: logZ is (1,S) instead of (T,S) and receives sum_t logZ[t,s] (update_latents keeps nothing else
+ * of it, :216), accumulated in time order.
  * H <= VBMP_LDS_MAX_H: two register-resident device forms, chosen by S: one series per 16-lane DPP row (S <= 32768: 4 series per wave, so that few
  * thousand series already cover every SIMD) and one series per lane (more series). */
 #define VBMP_LDS_CROSS_WORK 1
+#define VBMP_LDS_LOGZ_SUM 2
 #define VBMP_LDS_MAX_H 8        /* register-resident forms */
 #define VBMP_LDS_MAX_H_BLOCK 64 /* block-per-series form with LDS-resident matrices (8 < H; needs 5 H^2 words of LDS:
                                    fp64 up to H = 61); larger H return VBMP_ERR_ARG and the caller composes the recursion */
@@ -142,7 +145,7 @@ int vbmp_weighted_moments_f32(const float* X, const float* p, int64_t S, int64_t
   typedef struct vbmp_lds_args_##SUF {                                                                     \
     int64_t T, S, NB;                                                                                      \
     int H;                                                                                                 \
-    int flags; /* VBMP_LDS_CROSS_WORK: see above */                                                        \
+    int flags; /* VBMP_LDS_CROSS_WORK | VBMP_LDS_LOGZ_SUM: see above */                                    \
     const REAL *invQ, *ATQA_xx, *QA_xp_x, *A_Elogdet; /* (NB,H,H) x3, (NB) */                                 \
     const REAL *x0_P, *x0_eta, *x0_res;                /* (NB,H,H), (NB,H), (NB) */                           \
     const REAL* like_P;   int64_t lP_t, lP_s, lP_b;                                                           \

@@ -227,7 +227,7 @@ class LinearDynamicalSystems():
         if self.px is None:
             self.px = MultivariateNormal_vector_format(
                 mu=torch.zeros(tuple(y.shape[:-2]) + (self.hidden_dim, 1), device=y.device, dtype=y.dtype))
-        Sigma_t_tp1, Sigma_x0_x0, SE_x0, logZ, logZ_b = self.forward_backward_loop(y, u, r, dense_cross=False)
+        Sigma_t_tp1, Sigma_x0_x0, SE_x0, logZ, logZ_b = self.forward_backward_loop(y, u, r, sums_only=True)
         # time-integrated statistics: K10 cross-moment reductions (no (T, series, h, h) temporaries)
         Tn = y.shape[0]
         mu, Sig = self.px.mu, self.px.Sigma
@@ -349,11 +349,11 @@ class LinearDynamicalSystems():
                     for i in range(U.ndim - keep_last))
         return U[idx]
 
-    def forward_backward_loop(self, y, u, r, dense_cross=True):
+    def forward_backward_loop(self, y, u, r, sums_only=False):
         """Filter + smoother for every series in one persistent kernel launch (K9).
         Returns Sigma_t_tp1, Sigma_x0_x0, mu_x0, logZ, None like the reference (:332-383) and fills self.px.
-        dense_cross=False (update_latents: it reads the cross terms only through their time sum and slot T-1): the other
-        slots of the returned Sigma_t_tp1 are unspecified."""
+        sums_only=True (update_latents: it reads the cross terms only through their time sum and slot T-1, and logZ only through
+        its time sum): the other slots of the returned Sigma_t_tp1 are unspecified and logZ has one time step, the sum."""
         h = self.hidden_dim
         T_max = y.shape[0]
         sample_shape = tuple(y.shape[1:y.ndim - self.event_dim - self.batch_dim - 1])
@@ -369,7 +369,7 @@ class LinearDynamicalSystems():
             out = ops.lds_smoother(T_max, sample_shape, bo_shape, h, self.invQ, self.ATQA_x_x, self.QA_xp_x,
                                    self.A.ElogdetinvSigma(), x0.EinvSigma(), x0.EinvSigmamu(), x0_res,
                                    invSigma_like, invSigmamu_like.squeeze(-1), Residual_like, cu1, cu2, cu3,
-                                   dense_cross=dense_cross)
+                                   sums_only=sums_only)
         else:
             out = self._smoother_composed(T_max, sample_shape + bo_shape, invSigma_like, invSigmamu_like.squeeze(-1),
                                           Residual_like, cu1, cu2, cu3, x0_res)

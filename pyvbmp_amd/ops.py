@@ -299,9 +299,10 @@ def _norm3(X, T, sample_shape, bo_shape, inner):
 
 
 def lds_smoother(T, sample_shape, bo_shape, H, invQ, ATQA_xx, QA_xp_x, A_Elogdet, x0_P, x0_eta, x0_res,
-                 like_P, like_eta, like_res, cu1, cu2, cu3, dense_cross=True):
+                 like_P, like_eta, like_res, cu1, cu2, cu3, sums_only=False):
     """K9: one persistent launch of the information filter + smoother.
-    dense_cross=False: only slot T-1 of the returned Sigma_t_tp1 is meaningful (the rest is the sweeps' work buffer).
+    sums_only=True (what update_latents needs): only slot T-1 of the returned Sigma_t_tp1 is meaningful (the rest is the
+    sweeps' work buffer) and logZ has ONE time step holding its sum over time.
     System / prior parameters: bo_shape + (...).  Per-step operands: broadcastable to (T,)+sample+bo+(...).
     Returns dict of dense outputs shaped (T,)+sample+bo+(...) (and sample+bo+(...) for the x0 terms)."""
     dev = L.require_device(invQ, like_eta)
@@ -327,7 +328,7 @@ def lds_smoother(T, sample_shape, bo_shape, H, invQ, ATQA_xx, QA_xp_x, A_Elogdet
            "Sigma": torch.empty(lead + (H, H), dtype=dt, device=dev),
            "mu": torch.empty(lead + (H,), dtype=dt, device=dev),
            "Sigma_t_tp1": torch.empty(lead + (H, H), dtype=dt, device=dev),
-           "logZ": torch.empty(lead, dtype=dt, device=dev),
+           "logZ": torch.empty(((1,) + lead[1:]) if sums_only else lead, dtype=dt, device=dev),
            "Sigma_x0_x0": torch.empty(lead[1:] + (H, H), dtype=dt, device=dev),
            "mu_x0": torch.empty(lead[1:] + (H,), dtype=dt, device=dev),
            # time-integrated second moments, accumulated in the backward sweep's registers
@@ -335,7 +336,7 @@ def lds_smoother(T, sample_shape, bo_shape, H, invQ, ATQA_xx, QA_xp_x, A_Elogdet
            "sum_xpx": torch.empty(lead[1:] + (H, H), dtype=dt, device=dev)}
     a = L.LDS_ARGS[suf]()
     a.T, a.S, a.NB, a.H = T, S, NB, H
-    a.flags = 0 if dense_cross else L.LDS_CROSS_WORK
+    a.flags = (L.LDS_CROSS_WORK | L.LDS_LOGZ_SUM) if sums_only else 0
     for name, t in zip(("invQ", "ATQA_xx", "QA_xp_x", "A_Elogdet", "x0_P", "x0_eta", "x0_res"), keep):
         setattr(a, name, t.data_ptr())
     for (name, pre), (t, st) in zip((("like_P", "lP"), ("like_eta", "le"), ("like_res", "lr"), ("cu1", "c1"),

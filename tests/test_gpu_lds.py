@@ -353,7 +353,7 @@ def test_lds_fixed_point_shortcut_against_the_full_recursion(h, T, S, dtype, mod
 @pytest.mark.parametrize("T", [3, 60, 400])
 def test_lds_cross_covariances_dense_and_work_buffer_modes(T, form, smoother_form):
     """forward_backward_loop returns every Sigma_t_tp1[t] like the reference (:361-381); update_latents asks the kernel only for
-    slot T-1 and the time sums (vbmp_lds_args.flags & VBMP_LDS_CROSS_WORK).  Dense mode: all slots against the oracle; work
+    slot T-1, the time sums and sum_t logZ (vbmp_lds_args.flags = VBMP_LDS_CROSS_WORK | VBMP_LDS_LOGZ_SUM).  Dense mode: all slots against the oracle; work
     buffer mode: slot T-1 and every other output identical to the dense run."""
     from oracle import lds as olds
     from oracle import mnw as omnw
@@ -376,8 +376,11 @@ def test_lds_cross_covariances_dense_and_work_buffer_modes(T, form, smoother_for
     yo, uo, ro = olds.reshape_inputs(y, None, None, (6,), 1, 1)
     sm = olds.smoother(olds.latent_parms(A, h), x0, h, yo, uo, ro, obs, 0)
     assert_close(cross, sm["Sigma_t_tp1"], 1e-10, what="Sigma_t_tp1")
-    cross2, S002, m02, logZ2, _ = m.forward_backward_loop(yy, uu, rr, dense_cross=False)
-    assert torch.equal(cross2[-1], cross[-1]) and torch.equal(logZ2, logZ) and torch.equal(S002, S00) and torch.equal(m02, m0)
+    cross2, S002, m02, logZ2, _ = m.forward_backward_loop(yy, uu, rr, sums_only=True)
+    assert torch.equal(cross2[-1], cross[-1]) and torch.equal(S002, S00) and torch.equal(m02, m0)
+    assert logZ2.shape[0] == 1
+    assert_close(logZ2[0], logZ.sum(0), 1e-13, what="sum_t logZ")
+    assert_close(logZ, torch.as_tensor(sm["logZ"]).reshape(logZ.shape), 1e-10, what="logZ") if "logZ" in sm else None
     for f, v in dense.items():
         assert torch.equal(getattr(m.px, f), v), f
     for a, b in zip(m._time_sums, sums):
