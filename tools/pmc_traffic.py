@@ -28,6 +28,7 @@ CONFIGS = [
     ["--workload", "mnw_fwd"],
     ["--workload", "mnw_bwd"],
     ["--workload", "lds"],
+    ["--workload", "lds", "--dtype", "f32"],
     ["--workload", "dmbd"],
 ]
 
