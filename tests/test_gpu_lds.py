@@ -385,3 +385,46 @@ def test_lds_cross_covariances_dense_and_work_buffer_modes(T, form, smoother_for
         assert torch.equal(getattr(m.px, f), v), f
     for a, b in zip(m._time_sums, sums):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("mode", ["exact", "default"])
+def test_lds_fixed_point_shortcut_with_time_varying_controls(mode, smoother_flags):
+    """control and regression inputs that change every step leave the matrix recursion time-independent: the shortcut runs with
+    per-step control terms in its request ring (the instance whose controls are NOT hoisted).  Against the oracle at 1e-10, and
+    against the full recursion (bitwise under flag 0x800)."""
+    from oracle import lds as olds
+    from oracle import mnw as omnw
+    from oracle import niw as oniw
+    from pyvbmp_amd.models import LinearDynamicalSystems
+    T, S, h = 150, 7, 4
+    g = torch.Generator().manual_seed(77)
+    y = lorenz(T, S, g)[..., :5].contiguous()
+    u = torch.randn(T, S, 2, generator=g, dtype=torch.float64)
+    r = torch.randn(T, S, 1, generator=g, dtype=torch.float64)
+    outs = []
+    for flag in (0x8000, 0x800 if mode == "exact" else 0):
+        smoother_flags(flag)
+        torch.manual_seed(5)
+        m = LinearDynamicalSystems((5,), h, control_dim=2, regression_dim=1, latent_noise='shared', device=DEV, dtype=torch.float64)
+        m.update_latents(*m.reshape_inputs(y.to(DEV), u.to(DEV), r.to(DEV)))
+        outs.append({f: getattr(m.px, f).clone() for f in ("mu", "Sigma", "invSigma", "invSigmamu")} |
+                    {f: getattr(m, f).clone() for f in ("logZ", "SE_x_x", "SE_x_xpu", "SE_xpu_xpu", "SE_x0_x0", "SE_x0")})
+    full, short = outs
+    for k in full:
+        if mode == "exact":
+            assert torch.equal(full[k], short[k]), f"{k}: max abs diff {float((full[k] - short[k]).abs().max()):.3e}"
+        else:
+            assert_close(short[k], full[k], 1e-13, what=k)
+    mid = short["Sigma"][T // 2 - 2:T // 2 + 2]
+    if mode == "default":
+        assert torch.equal(mid[0], mid[1]) and torch.equal(mid[1], mid[2])  # the shortcut was taken
+    x0 = oniw.niw_new((h,), (), mu_init=m.x0.mu.cpu())
+    A = omnw.mnw_new((h, h + 3), (), mu_init=m.A.mu.cpu())
+    obs = omnw.mnw_new((5, h + 2), (), mu_init=m.obs_model.mu.cpu())
+    yo, uo, ro = olds.reshape_inputs(y, u, r, (5,), 3, 2)
+    sm = olds.smoother(olds.latent_parms(A, h), x0, h, yo, uo, ro, obs, 0)
+    for f in ("mu", "Sigma", "invSigma", "invSigmamu"):
+        assert_close(short[f], sm[f], 1e-10, what=f)
+    st = olds.latent_stats(sm, yo, uo, ro, (5,), 3, 2, (), 0)
+    assert_close(short["logZ"], st["logZ"], 1e-10, what="logZ")
+    assert_close(short["SE_x_xpu"], st["SE_x_xpu"], 1e-10, what="SE_x_xpu")
