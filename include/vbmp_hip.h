@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VBMP_ABI_VERSION 4
+#define VBMP_ABI_VERSION 5
 int vbmp_abi_version(void);
 
 /* K1 -- Ainv = A^-1 and logdet = log det A of B symmetric positive definite matrices.
@@ -156,11 +156,21 @@ int vbmp_weighted_moments_f32(const float* X, const float* p, int64_t S, int64_t
     const REAL* cu3;      int64_t c3_t, c3_s, c3_b;                                                           \
     REAL *invSigma, *invSigmamu, *Sigma, *mu, *Sigma_t_tp1, *logZ, *Sigma_x0_x0, *mu_x0;                      \
     REAL *sum_xx, *sum_xpx; /* nullable (S,H,H): time-integrated second moments, see above */                  \
+    /* optional first-moment sums (only where vbmp_lds_smoother_caps_* reports VBMP_LDS_CAP_OBS_SUMS, NULL otherwise): */ \
+    const REAL* y; int64_t y_t, y_s, y_b; /* observations (.., nobs), addressed like the per-step inputs; nullable */ \
+    int nobs, reserved_;                  /* 1 <= nobs <= 16 */                                                \
+    REAL *sum_mu, *sum_xy; /* nullable (S,H) = sum_t mu[t,s];  (S,H,nobs) = sum_t mu[t,s] y[t,s]' (needs y) */  \
   } vbmp_lds_args_##SUF;
 VBMP_DECL_LDS_ARGS(f64, double)
 VBMP_DECL_LDS_ARGS(f32, float)
 int vbmp_lds_smoother_f64(const vbmp_lds_args_f64* args, void* stream);
 int vbmp_lds_smoother_f32(const vbmp_lds_args_f32* args, void* stream);
+/* Which optional outputs the launch of `args` would fill (it depends on the device form chosen from H and S; only T, S, NB, H
+ * are read).  VBMP_LDS_CAP_OBS_SUMS: sum_mu / sum_xy -- the sums over time that update_latents (:179-190) otherwise forms with
+ * one more pass over mu and y -- are accumulated by the backward sweep (row-per-lane form); elsewhere they must be NULL. */
+#define VBMP_LDS_CAP_OBS_SUMS 1
+int vbmp_lds_smoother_caps_f64(const vbmp_lds_args_f64* args);
+int vbmp_lds_smoother_caps_f32(const vbmp_lds_args_f32* args);
 
 /* K10 -- time-integrated cross moments of the LDS statistics (LinearDynamicalSystems.update_latents,
  * models/LinearDynamicalSystems.py:173-190):  out[s,i,j] = sum_{t<Tn} a[t,s,i]*b[t,s,j] (+ sum_t M[t,s,i,j]).

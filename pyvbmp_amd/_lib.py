@@ -16,7 +16,7 @@ _c_i64 = ctypes.c_int64
 _c_int = ctypes.c_int
 _c_ptr = ctypes.c_void_p
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 
@@ -61,12 +61,15 @@ def lds_args_struct(cT):
         fields += [(n, P), (pre + "_t", _c_i64), (pre + "_s", _c_i64), (pre + "_b", _c_i64)]
     fields += [(n, P) for n in ("invSigma", "invSigmamu", "Sigma", "mu", "Sigma_t_tp1", "logZ", "Sigma_x0_x0", "mu_x0",
                                 "sum_xx", "sum_xpx")]
+    fields += [("y", P), ("y_t", _c_i64), ("y_s", _c_i64), ("y_b", _c_i64), ("nobs", _c_int), ("reserved_", _c_int),
+               ("sum_mu", P), ("sum_xy", P)]
     return type("vbmp_lds_args", (ctypes.Structure,), {"_fields_": fields})
 
 
 LDS_ARGS = {"f64": lds_args_struct(ctypes.c_double), "f32": lds_args_struct(ctypes.c_float)}
 LDS_CROSS_WORK = 1     # vbmp_lds_args.flags: only slot T-1 of Sigma_t_tp1 is wanted
 LDS_LOGZ_SUM = 2       # logZ is (1, S) and receives its sum over time
+LDS_CAP_OBS_SUMS = 1   # vbmp_lds_smoother_caps_*: sum_mu / sum_xy are filled by the launch
 LDS_MAX_H = 8          # register-resident smoother forms
 LDS_MAX_H_BLOCK = 64   # block-per-series form (LDS-resident matrices); also bounded by lds_block_fits()
 
@@ -128,6 +131,7 @@ SYMBOLS = {
     "vbmp_mixture_estep": _sig_estep,
     "vbmp_weighted_moments": _sig_wmom,
     "vbmp_lds_smoother": _sig_lds,
+    "vbmp_lds_smoother_caps": lambda T: [_c_ptr],
     "vbmp_tsum_outer": _sig_tsum,
     "vbmp_mnw_message": _sig_mnw_msg,
     "vbmp_hmm_forward_backward": _sig_hmm,

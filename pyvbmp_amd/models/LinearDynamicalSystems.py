@@ -235,6 +235,9 @@ class LinearDynamicalSystems():
         ts = _TimeSums()
         SE_x0_x0 = Sigma_x0_x0 + SE_x0 @ _T(SE_x0)
         sum_xx, sum_xpx = getattr(self, "_time_sums", (None, None))
+        sum_mu, sum_xy = getattr(self, "_obs_sums", (None, None))
+        if sum_mu is not None:
+            ts._sums[id(mv)] = (mv, sum_mu)  # sum_t mu_t came out of the backward sweep: no pass over mu for it
         SE_x_x = sum_xx if sum_xx is not None else ts(mv, mv, M=Sig)
         SE_xp_xp = SE_x_x - (mu[-1] @ _T(mu[-1]) + Sig[-1]) + SE_x0_x0
         SE_x_u = ts(mv, uv)
@@ -242,7 +245,7 @@ class LinearDynamicalSystems():
         SE_xp_x = (sum_xpx if sum_xpx is not None else ts(mv, mv, M=Sigma_t_tp1, b_from=1, steps=Tn - 1)) \
             + SE_x0 @ _T(mu[0]) + Sigma_t_tp1[-1]
         SE_x_r = ts(mv, rv)
-        SE_x_y = ts(mv, yv)
+        SE_x_y = sum_xy if sum_xy is not None else ts(mv, yv)
         # moments of the data alone do not change between VB iterations on the same (unmodified) tensors
         SE_u_u = self._data_moment(ts, "uu", uv, uv)
         SE_r_r = self._data_moment(ts, "rr", rv, rv)
@@ -369,7 +372,7 @@ class LinearDynamicalSystems():
             out = ops.lds_smoother(T_max, sample_shape, bo_shape, h, self.invQ, self.ATQA_x_x, self.QA_xp_x,
                                    self.A.ElogdetinvSigma(), x0.EinvSigma(), x0.EinvSigmamu(), x0_res,
                                    invSigma_like, invSigmamu_like.squeeze(-1), Residual_like, cu1, cu2, cu3,
-                                   sums_only=sums_only)
+                                   sums_only=sums_only, y=y.squeeze(-1) if (sums_only and len(self.offset) == 0) else None)
         else:
             out = self._smoother_composed(T_max, sample_shape + bo_shape, invSigma_like, invSigmamu_like.squeeze(-1),
                                           Residual_like, cu1, cu2, cu3, x0_res)
@@ -380,6 +383,7 @@ class LinearDynamicalSystems():
         self.px.logdetinvSigma = None
         # K9 accumulates the two matrix-valued time sums of update_latents in its backward sweep (None when composed)
         self._time_sums = (out.get("sum_xx"), out.get("sum_xpx"))
+        self._obs_sums = (out.get("sum_mu"), out.get("sum_xy"))  # first-moment sums, where the device form accumulates them
         return out["Sigma_t_tp1"], out["Sigma_x0_x0"], out["mu_x0"].unsqueeze(-1), out["logZ"], None
 
     def _smoother_composed(self, T, lead, P_like, eta_like, res_like, cu1, cu2, cu3, x0_res):

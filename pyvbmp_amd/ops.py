@@ -299,10 +299,12 @@ def _norm3(X, T, sample_shape, bo_shape, inner):
 
 
 def lds_smoother(T, sample_shape, bo_shape, H, invQ, ATQA_xx, QA_xp_x, A_Elogdet, x0_P, x0_eta, x0_res,
-                 like_P, like_eta, like_res, cu1, cu2, cu3, sums_only=False):
+                 like_P, like_eta, like_res, cu1, cu2, cu3, sums_only=False, y=None):
     """K9: one persistent launch of the information filter + smoother.
     sums_only=True (what update_latents needs): only slot T-1 of the returned Sigma_t_tp1 is meaningful (the rest is the
     sweeps' work buffer) and logZ has ONE time step holding its sum over time.
+    y (observations, broadcastable to (T,)+sample+bo+(nobs,), nobs <= 16): where the device form supports it the result also
+    holds "sum_mu" = sum_t mu[t] and "sum_xy" = sum_t mu[t] y[t]' (absent otherwise: the caller then uses K10).
     System / prior parameters: bo_shape + (...).  Per-step operands: broadcastable to (T,)+sample+bo+(...).
     Returns dict of dense outputs shaped (T,)+sample+bo+(...) (and sample+bo+(...) for the x0 terms)."""
     dev = L.require_device(invQ, like_eta)
@@ -347,6 +349,16 @@ def lds_smoother(T, sample_shape, bo_shape, H, invQ, ATQA_xx, QA_xp_x, A_Elogdet
         setattr(a, pre + "_b", st[2])
     for name, t in out.items():
         setattr(a, name, t.data_ptr())
+    if S > 0 and T > 0 and (getattr(lib, "vbmp_lds_smoother_caps_" + suf)(ctypes.byref(a)) & L.LDS_CAP_OBS_SUMS):
+        out["sum_mu"] = torch.empty(lead[1:] + (H,), dtype=dt, device=dev)
+        a.sum_mu = out["sum_mu"].data_ptr()
+        if y is not None and 1 <= y.shape[-1] <= 16:
+            nobs = y.shape[-1]
+            yk, yst = _norm3(y.to(dt), T, sample_shape, bo_shape, (nobs,))
+            steps.append(yk)  # kept alive until the launch
+            out["sum_xy"] = torch.empty(lead[1:] + (H, nobs), dtype=dt, device=dev)
+            a.y, a.y_t, a.y_s, a.y_b, a.nobs = yk.data_ptr(), yst[0], yst[1], yst[2], nobs
+            a.sum_xy = out["sum_xy"].data_ptr()
     if S > 0 and T > 0:
         fn = getattr(lib, "vbmp_lds_smoother_" + suf)
         L.call(fn, "vbmp_lds_smoother", ctypes.byref(a), L.stream_ptr(dev))
