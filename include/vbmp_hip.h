@@ -258,6 +258,15 @@ int vbmp_rows_affine_f64(const double* X, int64_t S, int k, const double* M, con
                          void* stream);
 int vbmp_rows_affine_f32(const float* X, int64_t S, int k, const float* M, const float* c, int n, float* out,
                          void* stream);
+/* K12 with the observation likelihood's scalar in the same pass: additionally q[s] = -1/2 x' P x + b' x + c0[0]
+ * (LinearDynamicalSystems.log_likelihood_function, models/LinearDynamicalSystems.py:244-266: invSigmamu_t and Residual of
+ * every (time, series) from ONE read of the observations).  P dense (k,k); b (k) or NULL; c0 one element in device memory or
+ * NULL; q dense (S).  1 <= k <= VBMP_ROWS_QUAD_MAX_K. */
+#define VBMP_ROWS_QUAD_MAX_K 16
+int vbmp_rows_affine_quad_f64(const double* X, int64_t S, int k, const double* M, const double* c, int n, double* out,
+                              const double* P, const double* b, const double* c0, double* q, void* stream);
+int vbmp_rows_affine_quad_f32(const float* X, int64_t S, int k, const float* M, const float* c, int n, float* out,
+                              const float* P, const float* b, const float* c0, float* q, void* stream);
 
 #ifdef __cplusplus
 }

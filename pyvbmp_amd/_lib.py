@@ -138,6 +138,8 @@ SYMBOLS = {
     "vbmp_weighted_matsum": _sig_matsum,
     "vbmp_weighted_matsum_cols": _sig_matsum_cols,
     "vbmp_rows_affine": _sig_rows,
+    # X, S, k, M, c, n, out, P, b, c0, q, stream
+    "vbmp_rows_affine_quad": lambda T: [_c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
 }
 DTYPES = {"f64": (torch.float64, ctypes.c_double), "f32": (torch.float32, ctypes.c_float)}
 

@@ -36,6 +36,76 @@ __global__ __launch_bounds__(256) void k_rows_affine(const T* __restrict__ X, in
   }
 }
 
+// K12 with the likelihood's scalar riding along: q[s] = -1/2 x' P x + b' x + c0 from the row the thread already holds (the
+// observation message of the LDS E-step needs both, LinearDynamicalSystems.log_likelihood_function :244-266: one pass over
+// the observations instead of K12 + K3a).  P (k x k), b (k), c0 (1 element, device memory).
+template <typename T, int KP>
+__global__ __launch_bounds__(256) void k_rows_affine_quad(const T* __restrict__ X, int64_t S, int k, const T* __restrict__ M,
+                                                          const T* __restrict__ c, int n, T* __restrict__ out,
+                                                          const T* __restrict__ P, const T* __restrict__ b,
+                                                          const T* __restrict__ c0, T* __restrict__ q) {
+  __shared__ T Ms[64 * KP + 64];
+  __shared__ T Ps[KP * KP + KP];
+  T* cs = Ms + 64 * KP;
+  T* bs = Ps + KP * KP;
+  for (int e = threadIdx.x; e < n * KP; e += 256) {
+    const int j = e / KP, i = e - j * KP;
+    Ms[e] = (i < k) ? M[j * k + i] : T(0);
+  }
+  for (int e = threadIdx.x; e < KP * KP; e += 256) {
+    const int j = e / KP, i = e - j * KP;
+    Ps[e] = (i < k && j < k) ? P[j * k + i] : T(0);
+  }
+  for (int j = threadIdx.x; j < n; j += 256) cs[j] = c ? c[j] : T(0);
+  for (int j = threadIdx.x; j < KP; j += 256) bs[j] = (b && j < k) ? b[j] : T(0);
+  const T cc = c0 ? c0[0] : T(0);
+  __syncthreads();
+  for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S; s += (int64_t)gridDim.x * 256) {
+    T x[KP];
+    const T* xr = X + s * k;
+#pragma unroll
+    for (int i = 0; i < KP; ++i) x[i] = (i < k) ? xr[i] : T(0);
+    T* o = out + s * n;
+    for (int j = 0; j < n; ++j) {
+      T acc = cs[j];
+#pragma unroll
+      for (int i = 0; i < KP; ++i) acc = __builtin_fma(Ms[j * KP + i], x[i], acc);
+      o[j] = acc;
+    }
+    T quad = T(0), lin = T(0);
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+      T t = T(0);
+#pragma unroll
+      for (int i = 0; i < KP; ++i) t = __builtin_fma(Ps[j * KP + i], x[i], t);
+      quad = __builtin_fma(x[j], t, quad);
+      lin = __builtin_fma(bs[j], x[j], lin);
+    }
+    q[s] = (T(-0.5) * quad + lin) + cc;
+  }
+}
+
+template <typename T, int KP>
+static int launch_rows_quad(const T* X, int64_t S, int k, const T* M, const T* c, int n, T* out, const T* P, const T* b,
+                            const T* c0, T* q, hipStream_t st) {
+  int64_t blocks = (S + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL((k_rows_affine_quad<T, KP>), dim3((unsigned)blocks), dim3(256), 0, st, X, S, k, M, c, n, out, P, b, c0, q);
+  return hipGetLastError() == hipSuccess ? 0 : VBMP_ERR_LAUNCH;
+}
+
+template <typename T>
+static int rows_quad_dispatch(const T* X, int64_t S, int k, const T* M, const T* c, int n, T* out, const T* P, const T* b,
+                              const T* c0, T* q, void* stream) {
+  if (S == 0) return 0;
+  if (!X || !M || !out || !P || !q || S < 0 || k < 1 || n < 1 || k > VBMP_ROWS_QUAD_MAX_K || n > VBMP_ROWS_MAX_DIM)
+    return VBMP_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (k <= 4) return launch_rows_quad<T, 4>(X, S, k, M, c, n, out, P, b, c0, q, st);
+  if (k <= 8) return launch_rows_quad<T, 8>(X, S, k, M, c, n, out, P, b, c0, q, st);
+  return launch_rows_quad<T, 16>(X, S, k, M, c, n, out, P, b, c0, q, st);
+}
+
 template <typename T, int KP>
 static int launch_rows(const T* X, int64_t S, int k, const T* M, const T* c, int n, T* out, hipStream_t st) {
   int64_t blocks = (S + 255) / 256;
@@ -66,5 +136,13 @@ int vbmp_rows_affine_f64(const double* X, int64_t S, int k, const double* M, con
 int vbmp_rows_affine_f32(const float* X, int64_t S, int k, const float* M, const float* c, int n, float* out,
                          void* stream) {
   return vbmp::rows_dispatch<float>(X, S, k, M, c, n, out, stream);
+}
+int vbmp_rows_affine_quad_f64(const double* X, int64_t S, int k, const double* M, const double* c, int n, double* out,
+                              const double* P, const double* b, const double* c0, double* q, void* stream) {
+  return vbmp::rows_quad_dispatch<double>(X, S, k, M, c, n, out, P, b, c0, q, stream);
+}
+int vbmp_rows_affine_quad_f32(const float* X, int64_t S, int k, const float* M, const float* c, int n, float* out,
+                              const float* P, const float* b, const float* c0, float* q, void* stream) {
+  return vbmp::rows_quad_dispatch<float>(X, S, k, M, c, n, out, P, b, c0, q, stream);
 }
 }

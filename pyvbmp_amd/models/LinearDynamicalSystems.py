@@ -318,6 +318,19 @@ class LinearDynamicalSystems():
         # a regressor that is the same for every (t, series) -- the usual bias column -- contributes constants: they ride along
         # in the two streaming kernels below instead of costing three more passes over (T, series, obs)
         const_r = Rc.numel() > 0 and all(s == 1 for s in Rc.shape[:-2]) and self.BTR_xp_y.ndim == 2
+        fused = const_r and Y.is_cuda and Y.dim() > 2 and Y.shape[-1] == 1 and self.obs_dim <= ops.ROWS_QUAD_MAX_K and \
+            self.invR.ndim == 2 and Y.numel() > 0
+        if fused:
+            # both halves of the observation message from ONE read of the observations (K12 with the scalar riding along)
+            cst = 0.5 * self.obs_model.ElogdetinvSigma() - 0.5 * self.obs_dim * _LOG2PI
+            lin = (_T(self.BTR_r_y) @ Rc).reshape(self.obs_dim)
+            quad_r = -0.5 * (_T(Rc) @ self.BTRB_r_r @ Rc).reshape(())
+            eta2, res2 = ops.rows_affine_quad(Y.reshape(-1, self.obs_dim), self.BTR_xp_y, -(self.BTRB_xp_r @ Rc).reshape(h),
+                                              self.invR, lin, cst + quad_r)
+            invSigmamu_t = eta2.reshape(tuple(Y.shape[:-2]) + (h, 1))
+            Residual = res2.reshape(tuple(Y.shape[:-2]))
+            invSigma_t_t = invSigma_t_t.expand(tuple(invSigmamu_t.shape[:-2]) + (h, h))
+            return invSigma_t_t, invSigmamu_t, Residual
         if const_r:
             invSigmamu_t = shared_matvec(self.BTR_xp_y, Y, bias=-(self.BTRB_xp_r @ Rc).reshape(h))
         elif self.BTR_xp_y.ndim == 2:

@@ -538,6 +538,31 @@ def rows_affine(X, M, c=None):
     return out
 
 
+ROWS_QUAD_MAX_K = 16
+
+
+def rows_affine_quad(X, M, c, P, b, c0):
+    """K12 + the quadratic form of the same rows in one pass: returns (M @ X[s] + c, -1/2 X[s]' P X[s] + b' X[s] + c0) for X (S, k),
+    M (n, k), c (n,) or None, P (k, k), b (k,) or None, c0 a 0-d / 1-element tensor or None; (S, n) and (S,)."""
+    dev = L.require_device(X, M, c, P, b, c0)
+    lib = L.load()
+    dt = X.dtype
+    Xc, Mc, Pc = X.contiguous(), M.to(dt).contiguous(), P.to(dt).contiguous()
+    cc = None if c is None else c.to(dt).contiguous()
+    bc = None if b is None else b.to(dt).contiguous()
+    c0c = None if c0 is None else c0.to(dt).reshape(1).contiguous()
+    S, k = Xc.shape
+    n = Mc.shape[0]
+    assert Mc.shape == (n, k) and Pc.shape == (k, k) and (cc is None or cc.shape == (n,)) and (bc is None or bc.shape == (k,))
+    out = torch.empty(S, n, dtype=dt, device=dev)
+    q = torch.empty(S, dtype=dt, device=dev)
+    if S > 0:
+        fn = getattr(lib, "vbmp_rows_affine_quad_" + L.suffix(dt))
+        L.call(fn, "vbmp_rows_affine_quad", L.ptr(Xc), S, k, L.ptr(Mc), L.ptr(cc), n, L.ptr(out), L.ptr(Pc), L.ptr(bc), L.ptr(c0c),
+               L.ptr(q), L.stream_ptr(dev))
+    return out, q
+
+
 MATSUM_MAX_COLS = 32
 
 
