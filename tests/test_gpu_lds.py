@@ -428,3 +428,55 @@ def test_lds_fixed_point_shortcut_with_time_varying_controls(mode, smoother_flag
     st = olds.latent_stats(sm, yo, uo, ro, (5,), 3, 2, (), 0)
     assert_close(short["logZ"], st["logZ"], 1e-10, what="logZ")
     assert_close(short["SE_x_xpu"], st["SE_x_xpu"], 1e-10, what="SE_x_xpu")
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 1e-4)])
+def test_lds_fixed_point_shortcut_on_a_slowly_converging_system(dtype, tol, smoother_flags):
+    """near-unit-root transition and a weakly informative observation model: the Riccati recursion creeps for hundreds of steps.
+    The shortcut must not freeze a sequence that still drifts: every output against the fp64 oracle at the north-star tolerance,
+    and against the full recursion."""
+    from oracle import lds as olds
+    from oracle import mnw as omnw
+    from oracle import niw as oniw
+    from pyvbmp_amd.models import LinearDynamicalSystems
+    T, S, h = 700, 6, 4
+    g = torch.Generator().manual_seed(11)
+    y = 0.3 * lorenz(T, S, g)[..., :3].contiguous()
+    torch.manual_seed(2)
+    m = LinearDynamicalSystems((3,), h, latent_noise='shared', device=DEV, dtype=dtype)
+    A0 = torch.cat((0.9995 * torch.eye(h, dtype=dtype), torch.zeros(h, 1, dtype=dtype)), -1)
+    m.A.mu = A0.to(DEV).reshape(m.A.mu.shape)
+    m.obs_model.mu = (0.02 * torch.randn(m.obs_model.mu.shape, generator=g, dtype=torch.float64)).to(dtype).to(DEV)
+    qs = 1e-4  # process-noise scale: E[invQ] = nu U grows by 1 / qs
+    W = m.A.invU
+    W.invU, W.U, W.logdet_invU = W.invU * qs, W.U / qs, W.logdet_invU + h * float(torch.log(torch.tensor(qs)))
+    m.set_latent_parms()
+    outs = []
+    for flag in (0x8000, 0):
+        smoother_flags(flag)
+        m.update_latents(*m.reshape_inputs(y.to(dtype).to(DEV)))
+        outs.append({f: getattr(m.px, f).clone() for f in ("mu", "Sigma", "invSigma", "invSigmamu")} |
+                    {f: getattr(m, f).clone() for f in ("logZ", "SE_x_x", "SE_x_xpu")})
+    full, short = outs
+    x0 = oniw.niw_new((h,), (), mu_init=m.x0.mu.cpu().double())
+    A = omnw.mnw_new((h, h + 1), (), mu_init=m.A.mu.cpu().double())
+    obs = omnw.mnw_new((3, h + 1), (), mu_init=m.obs_model.mu.cpu().double())
+    A["W"] = dict(A["W"])
+    A["W"]["invU"], A["W"]["U"] = A["W"]["invU"] * qs, A["W"]["U"] / qs
+    A["W"]["logdet_invU"] = A["W"]["logdet_invU"] + h * float(torch.log(torch.tensor(qs)))
+    yo, uo, ro = olds.reshape_inputs(y, None, None, (3,), 1, 1)
+    sm = olds.smoother(olds.latent_parms(A, h), x0, h, yo, uo, ro, obs, 0)
+    st = olds.latent_stats(sm, yo, uo, ro, (3,), 1, 1, (), 0)
+    from tests.helpers import relerr
+    errs = {f: (relerr(short[f], sm[f]), relerr(full[f], sm[f])) for f in ("mu", "Sigma", "invSigma", "invSigmamu")}
+    errs["logZ"] = (relerr(short["logZ"], st["logZ"]), relerr(full["logZ"], st["logZ"]))
+    errs["SE_x_xpu"] = (relerr(short["SE_x_xpu"], st["SE_x_xpu"]), relerr(full["SE_x_xpu"], st["SE_x_xpu"]))
+    print("normwise errors against the fp64 oracle (shortcut, full recursion):", {k: (f"{a:.1e}", f"{b:.1e}") for k, (a, b) in errs.items()})
+    for k, (a, b) in errs.items():
+        # the shortcut may not be further from the oracle than the north-star tolerance, or than the full recursion in the same
+        # precision is (an ill-conditioned system in fp32)
+        assert a <= max(tol, 2.0 * b), f"{k}: shortcut {a:.2e}, full recursion {b:.2e}"
+    # how slowly: the filtered covariance of the full recursion is still moving after 100 steps
+    d = (full["Sigma"][T // 2 + 1] - full["Sigma"][T // 2]).abs().max() / full["Sigma"][T // 2].abs().max()
+    d100 = (full["Sigma"][101] - full["Sigma"][100]).abs().max() / full["Sigma"][100].abs().max()
+    assert float(d100) > (1e-13 if dtype == torch.float64 else 1e-6), f"not a slow system: {float(d100):.2e} at t = 100, {float(d):.2e} at T / 2"
