@@ -1,4 +1,4 @@
-"""which Python lines of update_latents launch the small kernels? (torch.profiler, stacks grouped by the innermost pyvbmp_amd frame)"""
+"""how many device launches does each part of update_latents issue? (torch.profiler kernel counts of the parts run on their own)"""
 import collections, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -8,21 +8,30 @@ from tools.synth import lorenz
 T, S = 1000, 4096
 y = lorenz(T, S, torch.Generator(device="cuda").manual_seed(0), device="cuda", dtype=torch.float64)
 m = LinearDynamicalSystems((6,), 6, latent_noise='shared', device="cuda", dtype=torch.float64)
-inp = m.reshape_inputs(y)
+yy, uu, rr = m.reshape_inputs(y)
 for _ in range(3):
-    m.update_latents(*inp)
+    m.update_latents(yy, uu, rr)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
-    m.update_latents(*inp)
-    torch.cuda.synchronize()
-c = collections.Counter()
-names = collections.defaultdict(collections.Counter)
-for ev in prof.events():
-    if ev.device_type == torch.autograd.DeviceType.CPU and ev.cpu_parent is None and len(ev.kernels) > 0:
-        fr = [f for f in (ev.stack or []) if "pyvbmp_amd" in f]
-        key = (fr[0] if fr else "?")[-100:]
-        c[key] += len(ev.kernels)
-        names[key][ev.name] += len(ev.kernels)
-for k, v in c.most_common(70):
-    print(f"{v:4d}  {k}   {dict(names[k])}")
-print(sum(c.values()))
+
+
+def census(name, fn):
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        fn()
+        torch.cuda.synchronize()
+    ks = [ev for ev in prof.events() if ev.device_type == torch.autograd.DeviceType.CUDA]
+    c = collections.Counter(ev.name[:60] for ev in ks)
+    print(f"== {name}: {len(ks)} device activities")
+    for k, v in c.most_common(12):
+        print(f"   {v:3d} {k}")
+
+
+om, x0, A = m.obs_model, m.x0, m.A
+census("obs_model.EinvSigma", lambda: om.EinvSigma())
+census("obs_model.EXTinvUX", lambda: om.EXTinvUX())
+census("obs_model.EXTinvU", lambda: om.EXTinvU())
+census("obs_model.ElogdetinvSigma", lambda: om.ElogdetinvSigma())
+census("log_likelihood_function", lambda: m.log_likelihood_function(yy, rr))
+census("x0.EXTinvUX + ElogdetinvSigma + EinvSigma + EinvSigmamu", lambda: (x0.EXTinvUX(), x0.ElogdetinvSigma(), x0.EinvSigma(), x0.EinvSigmamu()))
+census("A.ElogdetinvSigma", lambda: A.ElogdetinvSigma())
+census("forward_backward_loop", lambda: m.forward_backward_loop(yy, uu, rr, sums_only=True))
+census("update_latents", lambda: m.update_latents(yy, uu, rr))
