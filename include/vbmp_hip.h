@@ -219,6 +219,21 @@ int vbmp_mnw_message_f32(const float* P, int64_t sP_s, int64_t sP_b, const float
                          const float* Add1, const float* Add2, const float* M, const float* C, const float* cvec,
                          float sign, float* ovec, float* omat, float* scal, int64_t S, int64_t NB, int m, int d,
                          void* stream);
+/* The same launch with the caller's residual formed in the kernel: res[s,b] = res_c[b] + sum_k res_w[k] * scal[s,b,k]
+ * (forward: Res = -q1/2 + q2/2 - (ld2 - ld1)/2, backward: transforms/MatrixNormalWishart.py:366-375 -- otherwise ~10 element-wise
+ * passes over strided slices of scal), and, with add_cvec != 0, ovec + cvec_b stored instead of ovec (the backward message's
+ * invSigmamu_x).  res_w: 8 weights in HOST memory; res_c: (NB) device memory or NULL; res: dense (S,NB) or NULL. */
+int vbmp_mnw_message_res_f64(const double* P, int64_t sP_s, int64_t sP_b, const double* e1, int64_t s1_s, int64_t s1_b,
+                             const double* e2, int64_t s2_s, int64_t s2_b, const double* e3, int64_t s3_s, int64_t s3_b,
+                             const double* Add1, const double* Add2, const double* M, const double* C, const double* cvec,
+                             double sign, double* ovec, double* omat, double* scal, int64_t S, int64_t NB, int m, int d,
+                             const double* res_w, const double* res_c, double* res, int add_cvec, void* stream);
+int vbmp_mnw_message_res_f32(const float* P, int64_t sP_s, int64_t sP_b, const float* e1, int64_t s1_s, int64_t s1_b,
+                             const float* e2, int64_t s2_s, int64_t s2_b, const float* e3, int64_t s3_s, int64_t s3_b,
+                             const float* Add1, const float* Add2, const float* M, const float* C, const float* cvec,
+                             float sign, float* ovec, float* omat, float* scal, int64_t S, int64_t NB, int m, int d,
+                             const float* res_w, const float* res_c, float* res, int add_cvec, void* stream);
+
 
 /* K11 -- discrete HMM forward-backward in log space (HMM.forward_backward_logits, models/HMM.py:72-105), the role
  * chain of DynamicMarkovBlanketDiscovery.  C independent chains of length Tn over K states; chain c uses the

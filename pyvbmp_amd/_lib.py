@@ -134,6 +134,8 @@ SYMBOLS = {
     "vbmp_lds_smoother_caps": lambda T: [_c_ptr],
     "vbmp_tsum_outer": _sig_tsum,
     "vbmp_mnw_message": _sig_mnw_msg,
+    # ... + res_w (host, 8 values), res_c, res, add_cvec before the stream
+    "vbmp_mnw_message_res": lambda T: _sig_mnw_msg(T)[:-1] + [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr],
     "vbmp_hmm_forward_backward": _sig_hmm,
     "vbmp_weighted_matsum": _sig_matsum,
     "vbmp_weighted_matsum_cols": _sig_matsum_cols,

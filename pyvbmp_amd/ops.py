@@ -439,10 +439,12 @@ def mnw_message_fusable(m, d):
     return pad(n) <= pad(p) <= L.MNW_MAX_DIM
 
 
-def mnw_message(P, e1, e2, e3, Add1, Add2, M, C, cvec, sign, bshape):
+def mnw_message(P, e1, e2, e3, Add1, Add2, M, C, cvec, sign, bshape, res_w=None, res_c=None, add_cvec=False):
     """K7/K8 sandwich kernel (see include/vbmp_hip.h).  P: sample+bshape*+(d,d); e1/e2/e3: sample+bshape*+(d,);
     Add1/Add2 (bshape,d,d); M (bshape,m,d); C (bshape,m,m); cvec (bshape,m) or None.
-    Returns ovec lead+(m,), omat lead+(m,m), scal lead+(8,) with lead = sample+bshape."""
+    Returns ovec lead+(m,), omat lead+(m,m), scal lead+(8,) with lead = sample+bshape.
+    res_w (8 Python floats): also returns res lead = res_c (bshape, or None) + sum_k res_w[k] scal[..., k], formed in the kernel;
+    add_cvec: ovec + cvec is returned in place of ovec."""
     dev = L.require_device(P, e1, e2, Add1, M, C)
     lib = L.load()
     dt = P.dtype
@@ -465,14 +467,24 @@ def mnw_message(P, e1, e2, e3, Add1, Add2, M, C, cvec, sign, bshape):
     ovec = torch.empty(lead + (m,), dtype=dt, device=dev)
     omat = torch.empty(lead + (m, m), dtype=dt, device=dev)
     scal = torch.empty(lead + (8,), dtype=dt, device=dev)
+    res = torch.empty(lead, dtype=dt, device=dev) if res_w is not None else None
+    rc = None if (res_c is None or res_w is None) else res_c.to(dt).expand(bshape).contiguous()
     if S > 0 and NB > 0:
         suf = L.suffix(dt)
-        fn = getattr(lib, "vbmp_mnw_message_" + suf)
         cT = L.DTYPES[suf][1]
-        L.call(fn, "vbmp_mnw_message", L.ptr(Pc), sP_s, sP_b, L.ptr(e1c), s1_s, s1_b, L.ptr(e2c), s2_s, s2_b, L.ptr(e3c),
-               s3_s, s3_b, L.ptr(A1), L.ptr(A2), L.ptr(Mc), L.ptr(Cc), L.ptr(cv), cT(float(sign)), L.ptr(ovec),
-               L.ptr(omat), L.ptr(scal), S, NB, m, d, L.stream_ptr(dev))
-    return ovec, omat, scal
+        if res_w is None and not add_cvec:
+            fn = getattr(lib, "vbmp_mnw_message_" + suf)
+            L.call(fn, "vbmp_mnw_message", L.ptr(Pc), sP_s, sP_b, L.ptr(e1c), s1_s, s1_b, L.ptr(e2c), s2_s, s2_b, L.ptr(e3c),
+                   s3_s, s3_b, L.ptr(A1), L.ptr(A2), L.ptr(Mc), L.ptr(Cc), L.ptr(cv), cT(float(sign)), L.ptr(ovec),
+                   L.ptr(omat), L.ptr(scal), S, NB, m, d, L.stream_ptr(dev))
+        else:
+            fn = getattr(lib, "vbmp_mnw_message_res_" + suf)
+            w8 = (cT * 8)(*[float(v) for v in (res_w if res_w is not None else [0.0] * 8)])
+            L.call(fn, "vbmp_mnw_message", L.ptr(Pc), sP_s, sP_b, L.ptr(e1c), s1_s, s1_b, L.ptr(e2c), s2_s, s2_b, L.ptr(e3c),
+                   s3_s, s3_b, L.ptr(A1), L.ptr(A2), L.ptr(Mc), L.ptr(Cc), L.ptr(cv), cT(float(sign)), L.ptr(ovec),
+                   L.ptr(omat), L.ptr(scal), S, NB, m, d, ctypes.cast(w8, ctypes.c_void_p) if res_w is not None else None,
+                   L.ptr(rc), L.ptr(res), 1 if add_cvec else 0, L.stream_ptr(dev))
+    return (ovec, omat, scal) if res_w is None else (ovec, omat, scal, res)
 
 
 def hmm_forward_backward(logits, trans, init, batch_shape, ptemp=1.0):

@@ -388,13 +388,14 @@ class MatrixNormalWishart():
         per_message = any(Px.shape[i] != 1 and Px.stride(i) != 0 for i in range(Px.ndim - 2 - len(bshape)))
         if per_message and ops.mnw_message_fusable(self.n, M1.shape[-1]):
             # one precision per message (BASELINE config 3): everything in ONE fused kernel (K7)
-            mu_y, Sigma_yy, sc = ops.mnw_message(Px, etax.squeeze(-1), eta.squeeze(-1), None, nV11, None, M1,
-                                                 self.invEinvSigma(), None, 1.0, bshape)
-            Res = -0.5 * sc[..., 0] + 0.5 * sc[..., 2] - 0.5 * (sc[..., 3] - sc[..., 1])
+            # Res = -q1/2 + q2/2 - (ld2 - ld1)/2 (- nV[-1,-1]/2 for the bias column) is formed by the kernel's epilogue
+            mu_y, Sigma_yy, sc, Res = ops.mnw_message(Px, etax.squeeze(-1), eta.squeeze(-1), None, nV11, None, M1,
+                                                      self.invEinvSigma(), None, 1.0, bshape,
+                                                      res_w=(-0.5, 0.5, 0.5, -0.5, 0.0, 0.0, 0.0, 0.0),
+                                                      res_c=-0.5 * nV[..., -1, -1] if self.pad_X else None)
             mu_y = mu_y.unsqueeze(-1)
             if self.pad_X:
                 mu_y = mu_y + M[..., -1:]
-                Res = Res - 0.5 * nV[..., -1, -1]
             return MultivariateNormal_vector_format(mu=mu_y, Sigma=Sigma_yy), Res
         # shared precision: one factorisation per expert, per-message work is GEMV (K1 + GEMMs)
         Sx, ld_x = ops.spd_inv_logdet(Px)
@@ -430,12 +431,15 @@ class MatrixNormalWishart():
             eta_y = jy + (G1 @ H11inv) @ jx
             # the marginal precision of y, Rm - G H^-1 G' + P_y, is never eliminated: its log-determinant and quadratic
             # form follow from the two eliminations the kernel runs anyway (Schur mode: scal[4] = q3, scal[5] = ld3 + ld_H)
-            ovec, Pxx, sc = ops.mnw_message(Py, etay.squeeze(-1), jy.squeeze(-1), eta_y.squeeze(-1), Rm, None, _T(G1), H11,
-                                            jx.squeeze(-1), -1.0, bshape)
-            eta_x = ovec.unsqueeze(-1) + jx
-            R = Res + 0.5 * (-sc[..., 0] + sc[..., 1] + sc[..., 4] - (sc[..., 5] - ld_H) + sc[..., 6] - sc[..., 7]) \
-                + 0.5 * self.ElogdetinvSigma() - 0.5 * J11 + 0.5 * px_dim * _LOG2PI
-            return MultivariateNormal_vector_format(invSigma=Pxx, invSigmamu=eta_x, logdetinvSigma=sc[..., 7]), R
+            # the kernel's epilogue forms the residual 1/2 (-q1 + ld1 + q3 - (ld3 - ld_H) + q4 - ld4) + per-expert constants and
+            # stores invSigmamu_x = ovec + jx directly
+            const = 0.5 * ld_H + 0.5 * self.ElogdetinvSigma() - 0.5 * J11 + 0.5 * px_dim * _LOG2PI
+            eta_x, Pxx, sc, R = ops.mnw_message(Py, etay.squeeze(-1), jy.squeeze(-1), eta_y.squeeze(-1), Rm, None, _T(G1), H11,
+                                                jx.squeeze(-1), -1.0, bshape, res_w=(-0.5, 0.5, 0.0, 0.0, 0.5, -0.5, 0.5, -0.5),
+                                                res_c=const, add_cvec=True)
+            if not (isinstance(Res, float) and Res == 0.0):
+                R = Res + R
+            return MultivariateNormal_vector_format(invSigma=Pxx, invSigmamu=eta_x.unsqueeze(-1), logdetinvSigma=sc[..., 7]), R
         Pxx, eta_x, R = self._marginalise(pY, +1.0, Res)
         pX = MultivariateNormal_vector_format(invSigma=Pxx, invSigmamu=eta_x)
         return pX, R - pX.Res()
