@@ -181,6 +181,105 @@ __global__ __launch_bounds__(256) void k_mixture_estep(const T* __restrict__ X, 
   }
 }
 
+// ------------------------------------------------------------------------------------ K3, symmetric-packed VALU form
+// x' P x = sum_i x_i (Q_ii x_i + sum_{j>i} Q_ij x_j) with Q_ii = P_ii, Q_ij = P_ij + P_ji (exact for any P): D(D+1)/2 + D FMAs per
+// (sample, component) instead of D^2 + D, the packed Q rows wave-uniform, i.e. scalar operands of the FMAs fetched through the
+// scalar cache.  The plain VALU form above is bound by that cache (8 bytes of P per FMA of every SIMD: measured 2.5x its FMA
+// time at K = 4, D = 16); here a thread owns NS samples, so one scalar fetch feeds NS FMAs, and the packing halves the fetches.
+// Q: (K, Dp (Dp + 1) / 2) rows i = 0.. with entries j = i..Dp-1; b (K, Dp); D == Dp.  Softmax, NA / logZ as in k_mixture_estep
+// (staged form).  Dynamic LDS: (K + 1) block partials | 256 NS rows of K + 1 | 256 rows of K + 1 running sums.
+template <typename T, int Dp, int NS>
+__global__ __launch_bounds__(256) void k_estep_sym(const T* __restrict__ X, int64_t S, int K, const T* __restrict__ Q,
+                                                   const T* __restrict__ b, const T* __restrict__ c, T* __restrict__ p,
+                                                   T* __restrict__ NA, T* __restrict__ logZ) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int TRI = Dp * (Dp + 1) / 2;
+  constexpr int ROWS = 256 * NS;
+  T* sNA = reinterpret_cast<T*>(smem_raw);
+  const int KS = K + 1;
+  T* sL = sNA + KS;            // ROWS x KS: log-likelihoods, then responsibilities of the chunk
+  T* sAcc = sL + ROWS * KS;    // 256 x KS: this thread's running sums
+  for (int k = 0; k <= K; ++k) sAcc[threadIdx.x * KS + k] = T(0);
+  const unsigned int kinv = 0xFFFFFFFFu / (unsigned int)K + 1u;
+  __syncthreads();
+  for (int64_t s0 = (int64_t)blockIdx.x * ROWS; s0 < S; s0 += (int64_t)gridDim.x * ROWS) {
+    T x[NS][Dp];
+    bool live[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      const int64_t sidx = s0 + threadIdx.x + 256 * u;
+      live[u] = sidx < S;
+      load_row<T, Dp>(X + (live[u] ? sidx : s0) * Dp, Dp, x[u]);
+    }
+    for (int k = 0; k < K; ++k) {
+      const T* __restrict__ Qk = Q + (int64_t)k * TRI;
+      const T* __restrict__ bk = b + (int64_t)k * Dp;
+      T l[NS];
+      const T ck = c[k];
+#pragma unroll
+      for (int u = 0; u < NS; ++u) l[u] = T(0);
+      int q = 0;
+#pragma unroll
+      for (int i = 0; i < Dp; ++i) {
+        T row[NS];
+#pragma unroll
+        for (int u = 0; u < NS; ++u) row[u] = T(0);
+#pragma unroll
+        for (int j = i; j < Dp; ++j) {
+          const T qij = Qk[q++];
+#pragma unroll
+          for (int u = 0; u < NS; ++u) row[u] = xfma(qij, x[u][j], row[u]);
+        }
+        const T bi = bk[i];
+#pragma unroll
+        for (int u = 0; u < NS; ++u) l[u] = xfma(x[u][i], xfma(T(-0.5), row[u], bi), l[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < NS; ++u) sL[(threadIdx.x + 256 * u) * KS + k] = l[u] + ck;
+    }
+    // softmax of my rows (only this thread touches them), running sums in my LDS slots
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      if (live[u]) {
+        T* row = sL + (threadIdx.x + 256 * u) * KS;
+        T mx = -INFINITY;
+        for (int k = 0; k < K; ++k) mx = row[k] > mx ? row[k] : mx;
+        T sum = T(0);
+        for (int k = 0; k < K; ++k) {
+          const T e = exp(row[k] - mx);
+          row[k] = e;
+          sum += e;
+        }
+        const T inv = T(1) / sum;
+        T* acc = sAcc + threadIdx.x * KS;
+        for (int k = 0; k < K; ++k) {
+          const T v = row[k] * inv;
+          row[k] = v;
+          acc[k] += v;
+        }
+        acc[K] += mx + log(sum);
+      }
+    }
+    __syncthreads();
+    const int64_t nrow = (S - s0) < ROWS ? (S - s0) : ROWS;
+    const int n = (int)nrow * K;
+    T* dst = p + s0 * K;
+    for (int e = threadIdx.x; e < n; e += 256) {
+      const int r = div_small(e, kinv, K), k = e - r * K;  // e / K, exact for e < 2^16
+      dst[e] = sL[r * KS + k];
+    }
+    __syncthreads();
+  }
+  for (int k = threadIdx.x; k <= K; k += 256) {
+    T tot = T(0);
+    for (int r = 0; r < 256; ++r) tot += sAcc[r * KS + k];
+    if (k < K)
+      atomicAdd(&NA[k], tot);
+    else
+      atomicAdd(logZ, tot);
+  }
+}
+
 // ------------------------------------------------------------------------------------ K4
 // Weighted moments (ref dists/NormalInverseWishart.py:72-84, dists/MultivariateNormal.py:93-99):
 //   Nk[bo,bi] = sum_s w ; SEx[bo,bi,:] = sum_s w x ; SExx[bo,bi,:,:] = sum_s w x x^T,
@@ -859,6 +958,51 @@ static int estep_dispatch(const T* X, int64_t S, int K, int D, const T* P, const
 }
 
 template <typename T>
+static int estep_sym_dispatch(const T* X, int64_t S, int K, int D, const T* Q, const T* b, const T* c, T* p, T* NA, T* logZ,
+                              void* stream) {
+  if (S == 0) return 0;
+  if (!X || !Q || !b || !c || !p || !NA || !logZ || S < 0 || K < 1 || K > VBMP_ESTEP_SYM_MAX_K) return VBMP_ERR_ARG;
+  if (D != 4 && D != 8 && D != 16 && D != 32) return VBMP_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+#ifndef VBMP_ES_NS64
+#define VBMP_ES_NS64 2
+#endif
+#ifndef VBMP_ES_NS32
+#define VBMP_ES_NS32 2
+#endif
+  constexpr int NS = sizeof(T) == 8 ? VBMP_ES_NS64 : VBMP_ES_NS32;  // samples per thread (A/B: tools/exp/build_variant.sh)
+  // samples per thread: NS while the block's LDS rows leave several blocks per CU, else one (measured: K = 8 prefers 1, K = 4
+  // prefers 2 in fp64, tools/exp/estep_sym_ab.py); D = 32 always one (registers)
+  auto smem_of = [&](int ns) { return (size_t)((K + 1) + (256 * ns + 256) * (K + 1)) * sizeof(T); };
+  int ns = (D == 32) ? 1 : NS;
+  if (ns > 1 && smem_of(ns) > 40 * 1024) ns = 1;
+  const size_t smem = smem_of(ns);
+  if (smem > 150 * 1024) return VBMP_ERR_ARG;
+  int64_t blocks = (S + 256 * ns - 1) / (256 * ns);
+  if (blocks > 256 * 8) blocks = 256 * 8;  // same-address atomics at the end are per block
+#define VBMP_ES(DPV, NSV)                                                                                                \
+  do {                                                                                                                   \
+    if (smem > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&k_estep_sym<T, DPV, NSV>),                \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)   \
+      return VBMP_ERR_LAUNCH;                                                                                            \
+    hipLaunchKernelGGL((k_estep_sym<T, DPV, NSV>), dim3((unsigned)blocks), dim3(256), smem, st, X, S, K, Q, b, c, p, NA, \
+                       logZ);                                                                                            \
+  } while (0)
+  if (D == 32) VBMP_ES(32, 1);
+  else if (ns == 1) {
+    if (D == 4) VBMP_ES(4, 1);
+    else if (D == 8) VBMP_ES(8, 1);
+    else VBMP_ES(16, 1);
+  } else {
+    if (D == 4) VBMP_ES(4, NS);
+    else if (D == 8) VBMP_ES(8, NS);
+    else VBMP_ES(16, NS);
+  }
+#undef VBMP_ES
+  return hipGetLastError() == hipSuccess ? 0 : VBMP_ERR_LAUNCH;
+}
+
+template <typename T>
 static int wmom_dispatch(const T* X, const T* p, int64_t S, int64_t Bo, int64_t Bi, int D, T* Nk, T* SEx, T* SExx,
                          void* stream) {
   if (S == 0 || Bo == 0 || Bi == 0) return 0;
@@ -901,6 +1045,10 @@ extern "C" {
   int vbmp_mixture_estep_##SUF(const T* X, int64_t S, int K, int D, const T* P, const T* b, const T* c, T* p, T* NA, \
                                T* logZ, void* stream) {                                                              \
     return estep_dispatch<T>(X, S, K, D, P, b, c, p, NA, logZ, stream);                                              \
+  }                                                                                                                  \
+  int vbmp_mixture_estep_sym_##SUF(const T* X, int64_t S, int K, int D, const T* Q, const T* b, const T* c, T* p,    \
+                                   T* NA, T* logZ, void* stream) {                                                   \
+    return estep_sym_dispatch<T>(X, S, K, D, Q, b, c, p, NA, logZ, stream);                                          \
   }                                                                                                                  \
   int vbmp_weighted_moments_##SUF(const T* X, const T* p, int64_t S, int64_t Bo, int64_t Bi, int D, T* Nk, T* SEx,   \
                                   T* SExx, void* stream) {                                                           \

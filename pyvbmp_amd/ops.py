@@ -222,11 +222,34 @@ def mixture_estep(X, P, b, c):
     p = torch.empty((S, K), dtype=dt, device=dev)
     acc = torch.zeros(K + 1, dtype=dt, device=dev)
     Pc, bc, cc = P.contiguous(), b.contiguous(), c.contiguous()  # named: a temporary's block could be reused before the launch
-    if S > 0:
+    if S > 0 and (D in (4, 8, 16) or (D == 32 and dt == torch.float32)) and K <= ESTEP_SYM_MAX_K and S >= 4096 \
+            and not _estep_sym_off:
+        # few components, many samples: symmetric-packed precisions as scalar operands (half the multiply-adds of x' P x,
+        # several samples per thread), see k_estep_sym
+        iu = _triu_idx(D, dev)
+        Ps = Pc + Pc.transpose(-1, -2)
+        Ps.diagonal(dim1=-2, dim2=-1).mul_(0.5)
+        Qc = Ps[:, iu[0], iu[1]].contiguous()
+        fn = getattr(lib, "vbmp_mixture_estep_sym_" + L.suffix(dt))
+        L.call(fn, "vbmp_mixture_estep", L.ptr(Xc), S, K, D, L.ptr(Qc), L.ptr(bc), L.ptr(cc), L.ptr(p),
+               L.ptr(acc), ctypes.c_void_p(acc.data_ptr() + K * acc.element_size()), L.stream_ptr(dev))
+    elif S > 0:
         fn = getattr(lib, "vbmp_mixture_estep_" + L.suffix(dt))
         L.call(fn, "vbmp_mixture_estep", L.ptr(Xc), S, K, D, L.ptr(Pc), L.ptr(bc), L.ptr(cc), L.ptr(p),
                    L.ptr(acc), ctypes.c_void_p(acc.data_ptr() + K * acc.element_size()), L.stream_ptr(dev))
     return p, acc[:K], acc[K]
+
+
+ESTEP_SYM_MAX_K = 8
+_estep_sym_off = False  # tests / A-B timing: force the other E-step forms
+_TRIU = {}
+
+
+def _triu_idx(D, dev):
+    key = (D, str(dev))
+    if key not in _TRIU:
+        _TRIU[key] = torch.triu_indices(D, D, device=dev)
+    return _TRIU[key]
 
 
 def weighted_moments(X, pv, n_sample_dims, mat_batch):

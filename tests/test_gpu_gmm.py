@@ -243,7 +243,8 @@ def test_quadform_mfma_and_valu_forms(S, Bo, Bi, D, dtype, smoother_flags):
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 @pytest.mark.parametrize("S,K,D", [(4099, 4, 16), (2500, 33, 12), (3001, 6, 40), (2048, 2, 64),
                                    (3000, 1, 4), (4099, 1, 16), (2049, 1, 2), (5000, 2, 4),  # K = 1: single-component mixture
-                                   (4100, 16, 16), (5000, 20, 8), (6000, 7, 12), (3333, 32, 8), (2100, 5, 24)])  # fused softmax: KG = 4, 8, 2, 8, 2
+                                   (4100, 16, 16), (5000, 20, 8), (6000, 7, 12), (3333, 32, 8), (2100, 5, 24),  # fused softmax: KG = 4, 8, 2, 8, 2
+                                   (8192, 8, 8), (4100, 3, 32), (70001, 5, 16), (4097, 8, 16), (9000, 7, 4)])  # symmetric-packed form
 def test_mixture_estep_mfma_and_valu_forms(S, K, D, dtype, smoother_flags):
     from pyvbmp_amd import ops
     g = torch.Generator().manual_seed(S + K)
@@ -256,12 +257,18 @@ def test_mixture_estep_mfma_and_valu_forms(S, K, D, dtype, smoother_flags):
     lse = torch.logsumexp(l, -1)
     pref = torch.exp(l - lse[:, None])
     tol = 1e-11 if dtype == torch.float64 else 1e-4
-    for flag in (0, 0x100, 0x4000):  # default (fused MFMA form where it applies) / VALU form / MFMA + separate softmax pass
-        smoother_flags(flag)
-        p, NA, logZ = ops.mixture_estep(X.to(DEV, dtype), P.to(DEV, dtype), b.to(DEV, dtype), c.to(DEV, dtype))
-        assert_close(p, pref, tol, what=f"p flag={flag}")
-        assert_close(NA, pref.sum(0), tol, what=f"NA flag={flag}")
-        assert_close(logZ, lse.sum(), tol, what=f"logZ flag={flag}")
+    # the product's choice (symmetric-packed VALU form for few components, D in {4, 8, 16, 32}, >= 4096 samples) / fused MFMA
+    # form where it applies / VALU form / MFMA + separate softmax pass
+    try:
+        for sym_off, flag in ((False, 0), (True, 0), (True, 0x100), (True, 0x4000)):
+            ops._estep_sym_off = sym_off
+            smoother_flags(flag)
+            p, NA, logZ = ops.mixture_estep(X.to(DEV, dtype), P.to(DEV, dtype), b.to(DEV, dtype), c.to(DEV, dtype))
+            assert_close(p, pref, tol, what=f"p flag={flag} sym_off={sym_off}")
+            assert_close(NA, pref.sum(0), tol, what=f"NA flag={flag} sym_off={sym_off}")
+            assert_close(logZ, lse.sum(), tol, what=f"logZ flag={flag} sym_off={sym_off}")
+    finally:
+        ops._estep_sym_off = False
 
 
 def test_gmm_graphed_update_matches_eager():
