@@ -104,12 +104,13 @@ int vbmp_mixture_estep_f32(const float* X, int64_t S, int K, int D, const float*
 /* K3, symmetric-packed form: the same E-step with the precision of component k passed as the packed upper triangle
  * Q[k] = (Q_00, Q_01, .., Q_0,D-1, Q_11, ..), Q_ii = P_ii, Q_ij = P_ij + P_ji (j > i), so that x' P x costs D (D + 1) / 2 + D
  * fused multiply-adds per (sample, component) with Q as wave-uniform scalar operands.  D in {4, 8, 16, 32} (no padding),
- * 1 <= K <= VBMP_ESTEP_SYM_MAX_K.  Other arguments as vbmp_mixture_estep. */
+ * 1 <= K <= VBMP_ESTEP_SYM_MAX_K.  lse (S) or NULL: the per-sample evidence logsumexp_k l[s,k] (the mixtures of linear
+ * transforms keep it, transforms/MixtureofLinearTransforms.py:36-43).  Other arguments as vbmp_mixture_estep. */
 #define VBMP_ESTEP_SYM_MAX_K 8
 int vbmp_mixture_estep_sym_f64(const double* X, int64_t S, int K, int D, const double* Q, const double* b,
-                               const double* c, double* p, double* NA, double* logZ, void* stream);
+                               const double* c, double* p, double* NA, double* logZ, double* lse, void* stream);
 int vbmp_mixture_estep_sym_f32(const float* X, int64_t S, int K, int D, const float* Q, const float* b, const float* c,
-                               float* p, float* NA, float* logZ, void* stream);
+                               float* p, float* NA, float* logZ, float* lse, void* stream);
 
 
 /* K4 -- weighted sufficient statistics (NormalInverseWishart.raw_update, dists/NormalInverseWishart.py:72-84;

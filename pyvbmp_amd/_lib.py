@@ -129,7 +129,7 @@ SYMBOLS = {
     "vbmp_niw_ss_update": _sig_niw,
     "vbmp_quadform_loglike": _sig_quadform,
     "vbmp_mixture_estep": _sig_estep,
-    "vbmp_mixture_estep_sym": _sig_estep,
+    "vbmp_mixture_estep_sym": lambda T: _sig_estep(T)[:-1] + [_c_ptr, _c_ptr],  # ... logZ, lse, stream
     "vbmp_weighted_moments": _sig_wmom,
     "vbmp_lds_smoother": _sig_lds,
     "vbmp_lds_smoother_caps": lambda T: [_c_ptr],

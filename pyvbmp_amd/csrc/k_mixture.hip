@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void k_mixture_estep(const T* __restrict__ X, 
 template <typename T, int Dp, int NS>
 __global__ __launch_bounds__(256) void k_estep_sym(const T* __restrict__ X, int64_t S, int K, const T* __restrict__ Q,
                                                    const T* __restrict__ b, const T* __restrict__ c, T* __restrict__ p,
-                                                   T* __restrict__ NA, T* __restrict__ logZ) {
+                                                   T* __restrict__ NA, T* __restrict__ logZ, T* __restrict__ lse_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int TRI = Dp * (Dp + 1) / 2;
   constexpr int ROWS = 256 * NS;
@@ -257,7 +257,9 @@ __global__ __launch_bounds__(256) void k_estep_sym(const T* __restrict__ X, int6
           row[k] = v;
           acc[k] += v;
         }
-        acc[K] += mx + log(sum);
+        const T lse = mx + log(sum);
+        acc[K] += lse;
+        if (lse_out) lse_out[s0 + threadIdx.x + 256 * u] = lse;  // per-sample evidence (mixtures of experts keep it)
       }
     }
     __syncthreads();
@@ -959,7 +961,7 @@ static int estep_dispatch(const T* X, int64_t S, int K, int D, const T* P, const
 
 template <typename T>
 static int estep_sym_dispatch(const T* X, int64_t S, int K, int D, const T* Q, const T* b, const T* c, T* p, T* NA, T* logZ,
-                              void* stream) {
+                              T* lse, void* stream) {
   if (S == 0) return 0;
   if (!X || !Q || !b || !c || !p || !NA || !logZ || S < 0 || K < 1 || K > VBMP_ESTEP_SYM_MAX_K) return VBMP_ERR_ARG;
   if (D != 4 && D != 8 && D != 16 && D != 32) return VBMP_ERR_ARG;
@@ -986,7 +988,7 @@ static int estep_sym_dispatch(const T* X, int64_t S, int K, int D, const T* Q, c
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)   \
       return VBMP_ERR_LAUNCH;                                                                                            \
     hipLaunchKernelGGL((k_estep_sym<T, DPV, NSV>), dim3((unsigned)blocks), dim3(256), smem, st, X, S, K, Q, b, c, p, NA, \
-                       logZ);                                                                                            \
+                       logZ, lse);                                                                                       \
   } while (0)
   if (D == 32) VBMP_ES(32, 1);
   else if (ns == 1) {
@@ -1047,8 +1049,8 @@ extern "C" {
     return estep_dispatch<T>(X, S, K, D, P, b, c, p, NA, logZ, stream);                                              \
   }                                                                                                                  \
   int vbmp_mixture_estep_sym_##SUF(const T* X, int64_t S, int K, int D, const T* Q, const T* b, const T* c, T* p,    \
-                                   T* NA, T* logZ, void* stream) {                                                   \
-    return estep_sym_dispatch<T>(X, S, K, D, Q, b, c, p, NA, logZ, stream);                                          \
+                                   T* NA, T* logZ, T* lse, void* stream) {                                           \
+    return estep_sym_dispatch<T>(X, S, K, D, Q, b, c, p, NA, logZ, lse, stream);                                     \
   }                                                                                                                  \
   int vbmp_weighted_moments_##SUF(const T* X, const T* p, int64_t S, int64_t Bo, int64_t Bi, int D, T* Nk, T* SEx,   \
                                   T* SExx, void* stream) {                                                           \

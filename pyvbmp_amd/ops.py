@@ -210,20 +210,26 @@ def quadform_loglike(X, P, b, c):
     return out.reshape(sample_shape + mat_batch)
 
 
-def mixture_estep(X, P, b, c):
+def mixture_estep(X, P, b, c, want_lse=False):
     """K3: fused responsibilities for a K-component mixture over dense samples X (S,D).
-    c must already include E log pi.  Returns p (S,K), NA (K), logZ ()."""
+    c must already include E log pi.  Returns p (S,K), NA (K), logZ ().
+    want_lse: also the per-sample evidence lse (S,) as a fourth value -- or None (nothing launched) when the shape is outside the
+    kernel form that provides it (the caller then composes the E-step)."""
     dev = L.require_device(X, P, b, c)
     lib = L.load()
     K, D = P.shape[0], P.shape[-1]
     dt = P.dtype
     Xc = X.to(dt).contiguous()
     S = Xc.shape[0]
+    sym = S > 0 and (D in (4, 8, 16) or (D == 32 and dt == torch.float32)) and K <= ESTEP_SYM_MAX_K and S >= 4096 \
+        and not _estep_sym_off
+    if want_lse and not sym:
+        return None
     p = torch.empty((S, K), dtype=dt, device=dev)
     acc = torch.zeros(K + 1, dtype=dt, device=dev)
+    lse = torch.empty(S, dtype=dt, device=dev) if want_lse else None
     Pc, bc, cc = P.contiguous(), b.contiguous(), c.contiguous()  # named: a temporary's block could be reused before the launch
-    if S > 0 and (D in (4, 8, 16) or (D == 32 and dt == torch.float32)) and K <= ESTEP_SYM_MAX_K and S >= 4096 \
-            and not _estep_sym_off:
+    if sym:
         # few components, many samples: symmetric-packed precisions as scalar operands (half the multiply-adds of x' P x,
         # several samples per thread), see k_estep_sym
         iu = _triu_idx(D, dev)
@@ -232,12 +238,12 @@ def mixture_estep(X, P, b, c):
         Qc = Ps[:, iu[0], iu[1]].contiguous()
         fn = getattr(lib, "vbmp_mixture_estep_sym_" + L.suffix(dt))
         L.call(fn, "vbmp_mixture_estep", L.ptr(Xc), S, K, D, L.ptr(Qc), L.ptr(bc), L.ptr(cc), L.ptr(p),
-               L.ptr(acc), ctypes.c_void_p(acc.data_ptr() + K * acc.element_size()), L.stream_ptr(dev))
+               L.ptr(acc), ctypes.c_void_p(acc.data_ptr() + K * acc.element_size()), L.ptr(lse), L.stream_ptr(dev))
     elif S > 0:
         fn = getattr(lib, "vbmp_mixture_estep_" + L.suffix(dt))
         L.call(fn, "vbmp_mixture_estep", L.ptr(Xc), S, K, D, L.ptr(Pc), L.ptr(bc), L.ptr(cc), L.ptr(p),
                    L.ptr(acc), ctypes.c_void_p(acc.data_ptr() + K * acc.element_size()), L.stream_ptr(dev))
-    return p, acc[:K], acc[K]
+    return (p, acc[:K], acc[K], lse) if want_lse else (p, acc[:K], acc[K])
 
 
 ESTEP_SYM_MAX_K = 8

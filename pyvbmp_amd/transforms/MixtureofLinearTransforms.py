@@ -10,6 +10,8 @@ update).
 """
 import torch
 
+from .. import ops
+
 from ..dists.Dirichlet import Dirichlet
 from ..dists.MultivariateNormal_vector_format import MultivariateNormal_vector_format
 from .MatrixNormalGamma import MatrixNormalGamma
@@ -45,8 +47,21 @@ class MixtureofLinearTransforms():
         self.logZ = logZ.squeeze(-1)
 
     def update_assignments(self, X, Y):
+        W = self.W
+        if self.batch_dim == 0 and hasattr(W, '_joint_quadratic') and W.event_dim == 2 and X.is_cuda and X.ndim >= 3 and Y.ndim == X.ndim \
+                and tuple(X.shape[:-2]) == tuple(Y.shape[:-2]):
+            # unbatched mixture over dense samples: likelihood, softmax and evidence in ONE fused launch (K3, symmetric-packed
+            # form) on the stacked vector z = [x; y]; None when the shape is outside that kernel form
+            P, b, c = W._joint_quadratic()
+            sample = tuple(X.shape[:-2])
+            Z = torch.cat((X, Y), dim=-2).reshape(-1, X.shape[-2] + Y.shape[-2])
+            hit = ops.mixture_estep(Z, P, b, c + self.pi.loggeomean(), want_lse=True)
+            if hit is not None:
+                self.p = hit[0].reshape(sample + (self.dim,))
+                self.logZ = hit[3].reshape(sample)
+                return
         # W.Elog_like is one K3a launch: the joint quadratic form of z = [x; y] for every (sample, expert)
-        self._normalise(self.W.Elog_like(X.unsqueeze(-3), Y.unsqueeze(-3)) + self.pi.loggeomean())
+        self._normalise(W.Elog_like(X.unsqueeze(-3), Y.unsqueeze(-3)) + self.pi.loggeomean())
 
     def update_assignments_given_pX_pY(self, pX, pY):
         self._normalise(self.W.Elog_like_given_pX_pY(pX.unsqueeze(-3), pY.unsqueeze(-3)) + self.pi.loggeomean())

@@ -105,3 +105,36 @@ def test_gated_mixture_golden(golden, case):
     assert_close(m.A.mu, c["upd_A_mu"], 1e-9, what="upd A_mu")
     check_ard(m.pi.beta, c, "upd_pi_")
     assert_close(m.ELBO_last, c["upd_ELBO"], 1e-9, what="upd ELBO")
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 1e-4)])
+@pytest.mark.parametrize("n,p,K,N,pad", [(8, 8, 8, 20000, False), (3, 4, 5, 9001, True), (4, 4, 3, 4096, False)])
+def test_mixture_of_linear_transforms_fused_estep(n, p, K, N, pad, dtype, tol):
+    """MixtureofLinearTransforms.update_assignments on many dense samples takes ONE fused launch (symmetric-packed K3 on the stacked
+    z = [x; y], with the per-sample evidence): responsibilities and evidence against the composed route (K3a + softmax in torch)"""
+    from pyvbmp_amd import ops
+    from pyvbmp_amd.transforms import MixtureofLinearTransforms
+    g = torch.Generator().manual_seed(n * 100 + K)
+    X = torch.randn(N, p, 1, generator=g, dtype=torch.float64)
+    Y = torch.randn(n, p, generator=g, dtype=torch.float64) @ X + 0.3 * torch.randn(N, n, 1, generator=g, dtype=torch.float64)
+    torch.manual_seed(1)
+    m = MixtureofLinearTransforms(n, p, K, pad_X=pad, device=DEV, dtype=dtype)
+    Xd, Yd = X.to(DEV, dtype), Y.to(DEV, dtype)
+    m.raw_update(Xd[:500], Yd[:500], iters=2)   # move the experts off their prior
+    launched = []
+    from pyvbmp_amd import _lib
+    _lib.launch_hooks = (lambda name: launched.append(name), lambda name: None)
+    try:
+        m.update_assignments(Xd, Yd)
+    finally:
+        _lib.launch_hooks = None
+    fusable = (n + p + (0 if not pad else 0)) in (4, 8, 16) or ((n + p) == 32 and dtype == torch.float32)
+    assert ("vbmp_mixture_estep" in launched) == fusable, launched
+    p_f, lz_f = m.p.clone(), m.logZ.clone()
+    try:
+        ops._estep_sym_off = True
+        m.update_assignments(Xd, Yd)
+    finally:
+        ops._estep_sym_off = False
+    assert_close(p_f, m.p, tol, what="responsibilities")
+    assert_close(lz_f, m.logZ, tol, what="per-sample evidence")
