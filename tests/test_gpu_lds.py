@@ -199,12 +199,10 @@ def test_lds_smoother_every_hidden_dim_both_forms(h, form, smoother_form):
     assert_close(m.SE_x_xpu, st["SE_x_xpu"], 1e-10, what="SE_x_xpu")
 
 
-@pytest.mark.parametrize("inverses", ["one wave per matrix", "block-wide"])
 @pytest.mark.parametrize("case", LDS_CASES)
-def test_lds_block_form_matches_golden(golden, case, inverses, smoother_flags):
-    """K9's block-per-series form (LDS-resident matrices, meant for 8 < hidden <= 64) forced onto the golden cases, with both
-    forms of its Gauss-Jordan inverses (flag 0x1000: the block-wide one)"""
-    smoother_flags(0x200 | (0x1000 if inverses == "block-wide" else 0))
+def test_lds_block_form_matches_golden(golden, case, smoother_flags):
+    """K9's block-per-series form (LDS-resident matrices, meant for 8 < hidden <= 64) forced onto the golden cases"""
+    smoother_flags(0x200)
     c = golden("lds")[case]
     m = _make(c)
     dev = lambda k: c[k].to(DEV) if k in c else None  # noqa: E731
