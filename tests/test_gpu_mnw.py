@@ -180,6 +180,32 @@ def test_rows_affine(S, k, n, bias, dtype):
         assert_close(out, ref, 1e-12 if dtype == torch.float64 else 1e-5, what="rows_affine")
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("S,k,n,opt", [(1, 1, 1, True), (1000, 3, 5, True), (70001, 6, 6, True), (5000, 9, 20, False), (4097, 16, 3, True),
+                                       (300, 6, 64, False)])
+def test_rows_affine_quad(S, k, n, opt, dtype):
+    """K12 with the likelihood's scalar in the same pass: M x + c and -1/2 x'Px + b'x + c0 per row against plain products;
+    opt=False: without the optional bias / linear term / constant"""
+    from pyvbmp_amd import ops
+    g = torch.Generator().manual_seed(S + 7 * k)
+    X = torch.randn(S, k, generator=g, dtype=torch.float64)
+    M = torch.randn(n, k, generator=g, dtype=torch.float64)
+    A = torch.randn(k, k + 2, generator=g, dtype=torch.float64)
+    P = A @ A.T / k
+    c = torch.randn(n, generator=g, dtype=torch.float64) if opt else None
+    b = torch.randn(k, generator=g, dtype=torch.float64) if opt else None
+    c0 = torch.randn((), generator=g, dtype=torch.float64) if opt else None
+    dev = lambda t: None if t is None else t.to(dtype).to(DEV)  # noqa: E731
+    out, q = ops.rows_affine_quad(dev(X), dev(M), dev(c), dev(P), dev(b), dev(c0))
+    Xd, Md, Pd = X.to(dtype).double(), M.to(dtype).double(), P.to(dtype).double()
+    ref = Xd @ Md.T + (0 if c is None else c.to(dtype).double())
+    qref = -0.5 * ((Xd @ Pd) * Xd).sum(-1) + (0 if b is None else Xd @ b.to(dtype).double()) + (0 if c0 is None else c0.to(dtype).double())
+    assert out.shape == (S, n) and q.shape == (S,)
+    tol = 1e-12 if dtype == torch.float64 else 1e-5
+    assert_close(out, ref, tol, what="M x + c")
+    assert_close(q, qref, tol, what="quadratic form")
+
+
 def test_shared_matvec_routes_many_rows_through_k12():
     from pyvbmp_amd._common import shared_matvec
     g = torch.Generator().manual_seed(3)
