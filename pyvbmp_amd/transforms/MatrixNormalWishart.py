@@ -428,7 +428,7 @@ class MatrixNormalWishart():
                 jx = torch.zeros(tuple(H.shape[:-1]) + (1,), device=self.device, dtype=self.dtype)
                 J11 = 0.0
             H11inv, ld_H = ops.spd_inv_logdet(H11)                  # per expert
-            eta_y = jy + (G1 @ H11inv) @ jx
+            eta_y = jy + (G1 @ H11inv) @ jx if self.pad_X else jy   # (no bias column: j_x = 0, no pass over the messages)
             # the marginal precision of y, Rm - G H^-1 G' + P_y, is never eliminated: its log-determinant and quadratic
             # form follow from the two eliminations the kernel runs anyway (Schur mode: scal[4] = q3, scal[5] = ld3 + ld_H)
             # the kernel's epilogue forms the residual 1/2 (-q1 + ld1 + q3 - (ld3 - ld_H) + q4 - ld4) + per-expert constants and
