@@ -480,3 +480,45 @@ def test_lds_fixed_point_shortcut_on_a_slowly_converging_system(dtype, tol, smoo
     d = (full["Sigma"][T // 2 + 1] - full["Sigma"][T // 2]).abs().max() / full["Sigma"][T // 2].abs().max()
     d100 = (full["Sigma"][101] - full["Sigma"][100]).abs().max() / full["Sigma"][100].abs().max()
     assert float(d100) > (1e-13 if dtype == torch.float64 else 1e-6), f"not a slow system: {float(d100):.2e} at t = 100, {float(d):.2e} at T / 2"
+
+
+@pytest.mark.parametrize("mode", ["exact", "default"])
+def test_lds_fixed_point_shortcut_with_a_batch_of_systems(mode, smoother_flags):
+    """two systems with different parameters share every wave (series s belongs to system s % 2): each 16-lane row freezes on its
+    own recursion.  Long horizon so that the shortcut is taken; against the oracle and the full recursion."""
+    from oracle import lds as olds
+    from oracle import mnw as omnw
+    from oracle import niw as oniw
+    from pyvbmp_amd.models import LinearDynamicalSystems
+    T, S, h, NB = 260, 5, 4, 2
+    g = torch.Generator().manual_seed(41)
+    y = lorenz(T, S, g)[..., :5].contiguous()
+    outs = []
+    for flag in (0x8000, 0x800 if mode == "exact" else 0):
+        smoother_flags(flag)
+        torch.manual_seed(9)
+        m = LinearDynamicalSystems((5,), h, latent_noise='shared', batch_shape=(NB,), device=DEV, dtype=torch.float64)
+        m.expand_to_batch = True
+        m.update_latents(*m.reshape_inputs(y.to(DEV)))
+        outs.append({f: getattr(m.px, f).clone() for f in ("mu", "Sigma", "invSigma", "invSigmamu")} |
+                    {f: getattr(m, f).clone() for f in ("logZ", "SE_x_x", "SE_x_xpu", "SE_y_xr")})
+    full, short = outs
+    for k in full:
+        if mode == "exact":
+            assert torch.equal(full[k], short[k]), f"{k}: max abs diff {float((full[k] - short[k]).abs().max()):.3e}"
+        else:
+            assert_close(short[k], full[k], 1e-13, what=k)
+    if mode == "default":
+        mid = short["Sigma"][T // 2 - 2:T // 2 + 2]
+        assert torch.equal(mid[0], mid[1]) and torch.equal(mid[1], mid[2])  # the shortcut was taken
+        assert not torch.equal(mid[0][:, 0], mid[0][:, 1])                  # ... and the two systems differ
+    x0 = oniw.niw_new((h,), (NB,), mu_init=m.x0.mu.cpu())
+    A = omnw.mnw_new((h, h + 1), (NB,), mu_init=m.A.mu.cpu())
+    obs = omnw.mnw_new((5, h + 1), (NB,), mu_init=m.obs_model.mu.cpu())
+    yo, uo, ro = olds.reshape_inputs(y, None, None, (5,), 1, 1, batch_shape=(NB,), expand_to_batch=True)
+    sm = olds.smoother(olds.latent_parms(A, h), x0, h, yo, uo, ro, obs, 0)
+    for f in ("mu", "Sigma", "invSigma", "invSigmamu"):
+        assert_close(short[f], sm[f], 1e-10, what=f)
+    st = olds.latent_stats(sm, yo, uo, ro, (5,), 1, 1, (NB,), 0)
+    for f in ("logZ", "SE_x_xpu", "SE_y_xr"):
+        assert_close(short[f], st[f], 1e-10, what=f)
