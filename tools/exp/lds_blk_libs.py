@@ -7,7 +7,7 @@ from pyvbmp_amd import _lib
 from pyvbmp_amd.models import LinearDynamicalSystems
 default = _lib.LIB_PATH
 h, T, S = 52, 100, 20
-for dt in (torch.float64,):
+for dt in (torch.float64, torch.float32):
     g = torch.Generator(device="cuda").manual_seed(0)
     y = torch.randn(T, S, 6, generator=g, device="cuda", dtype=dt).cumsum(0) * 0.05
     m = LinearDynamicalSystems((6,), h, latent_noise='shared', device="cuda", dtype=dt)
