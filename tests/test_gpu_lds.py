@@ -214,8 +214,9 @@ def test_lds_block_form_matches_golden(golden, case, smoother_flags):
         assert_close(getattr(m, f), c["it1_" + f], 1e-10, what=f)
 
 
-@pytest.mark.parametrize("h,dtype,tol", [(9, torch.float64, 1e-10), (12, torch.float64, 1e-10), (21, torch.float64, 1e-10),
-                                         (52, torch.float64, 1e-10), (61, torch.float64, 1e-10), (12, torch.float32, 1e-4),
+@pytest.mark.parametrize("h,dtype,tol", [(9, torch.float64, 1e-10), (12, torch.float64, 1e-10), (14, torch.float64, 1e-10), (21, torch.float64, 1e-10),
+                                         (33, torch.float64, 1e-10), (14, torch.float32, 1e-4),
+                                         (52, torch.float64, 1e-10), (60, torch.float64, 1e-10), (61, torch.float64, 1e-10), (12, torch.float32, 1e-4),
                                          (52, torch.float32, 1e-4), (64, torch.float32, 1e-4)])
 def test_lds_block_form_vs_oracle_and_composed(h, dtype, tol, monkeypatch):
     """hidden dimensions beyond the register forms (52 = the latent of the flocking DMBD): the block-per-series kernel
