@@ -293,12 +293,12 @@ class LinearDynamicalSystems():
         h = self.hidden_dim
         self.invQ = self.A.EinvSigma()
         ATQA = self.A.EXTinvUX()
-        self.ATQA_x_x = ATQA[..., :h, :h]
+        self.ATQA_x_x = ATQA[..., :h, :h].contiguous()  # (dense once here: the smoother launch of every E-step wants it dense)
         self.invATQA_x_x, self.logdetATQA_x_x = ops.spd_inv_logdet(self.ATQA_x_x)
         self.ATQA_x_u = ATQA[..., :h, h:]
         self.ATQA_u_u = ATQA[..., h:, h:]
         QA = self.A.EinvUX()
-        self.QA_xp_x = QA[..., :, :h]
+        self.QA_xp_x = QA[..., :, :h].contiguous()
         self.QA_xp_u = QA[..., :, h:]
 
     def log_likelihood_function(self, Y, R):
