@@ -145,10 +145,21 @@ int vbmp_weighted_moments_f32(const float* X, const float* p, int64_t S, int64_t
  * final contents are unspecified, and the kernel may skip their stores.
  * flags & VBMP_LDS_LOGZ_SUM: logZ is (1,S) instead of (T,S) and receives sum_t logZ[t,s] (update_latents keeps nothing else
  * of it, :216), accumulated in time order.
+ * Fixed-point shortcut (row-per-lane form, likelihood precision independent of time, lP_t == 0): the matrix half of the
+ * recursion is then a Riccati iteration with constant coefficients; once it has stopped moving the kernel runs only the mean
+ * recursion on the frozen matrices (the reference recomputes the same matrices at every step, :268-330).  Accuracy contract:
+ *   default                          stop at a bitwise repeat of the filtered precision, OR after 8 consecutive steps that each moved
+ *                                    it by <= 4 ulp of its row's largest entry, moved it by <= 4 ulp in total, and only while the
+ *                                    recursion was seen to contract by >= 2x per 8 steps: outputs equal the literal recursion's to
+ *                                    its own last-bit wander (<= 1e-13 fp64 / 2e-6 fp32 normwise per tensor in the tests)
+ *   flags & VBMP_LDS_FIXED_POINT_EXACT   stop only at a bitwise repeat: every output is bit for bit that of the literal recursion
+ *   flags & VBMP_LDS_FIXED_POINT_OFF     never stop: the literal recursion at every step
  * H <= VBMP_LDS_MAX_H: two register-resident device forms, chosen by S: one series per 16-lane DPP row (S <= 32768: 4 series per wave, so that few
  * thousand series already cover every SIMD) and one series per lane (more series). */
 #define VBMP_LDS_CROSS_WORK 1
 #define VBMP_LDS_LOGZ_SUM 2
+#define VBMP_LDS_FIXED_POINT_EXACT 4
+#define VBMP_LDS_FIXED_POINT_OFF 8
 #define VBMP_LDS_MAX_H 8        /* register-resident forms */
 #define VBMP_LDS_MAX_H_BLOCK 64 /* block-per-series form with LDS-resident matrices (8 < H; needs 5 H^2 words of LDS:
                                    fp64 up to H = 61); larger H return VBMP_ERR_ARG and the caller composes the recursion */
@@ -156,7 +167,7 @@ int vbmp_weighted_moments_f32(const float* X, const float* p, int64_t S, int64_t
   typedef struct vbmp_lds_args_##SUF {                                                                     \
     int64_t T, S, NB;                                                                                      \
     int H;                                                                                                 \
-    int flags; /* VBMP_LDS_CROSS_WORK | VBMP_LDS_LOGZ_SUM: see above */                                    \
+    int flags; /* VBMP_LDS_CROSS_WORK | VBMP_LDS_LOGZ_SUM | VBMP_LDS_FIXED_POINT_*: see above */              \
     const REAL *invQ, *ATQA_xx, *QA_xp_x, *A_Elogdet; /* (NB,H,H) x3, (NB) */                                 \
     const REAL *x0_P, *x0_eta, *x0_res;                /* (NB,H,H), (NB,H), (NB) */                           \
     const REAL* like_P;   int64_t lP_t, lP_s, lP_b;                                                           \

@@ -69,6 +69,8 @@ def lds_args_struct(cT):
 LDS_ARGS = {"f64": lds_args_struct(ctypes.c_double), "f32": lds_args_struct(ctypes.c_float)}
 LDS_CROSS_WORK = 1     # vbmp_lds_args.flags: only slot T-1 of Sigma_t_tp1 is wanted
 LDS_LOGZ_SUM = 2       # logZ is (1, S) and receives its sum over time
+# fixed-point shortcut of the smoother (VBMP_LDS_FIXED_POINT_EXACT / _OFF; accuracy contract in include/vbmp_hip.h)
+LDS_FIXED_POINT = {"auto": 0, "exact": 4, "off": 8}
 LDS_CAP_OBS_SUMS = 1   # vbmp_lds_smoother_caps_*: sum_mu / sum_xy are filled by the launch
 LDS_MAX_H = 8          # register-resident smoother forms
 LDS_MAX_H_BLOCK = 64   # block-per-series form (LDS-resident matrices); also bounded by lds_block_fits()

@@ -69,6 +69,11 @@ class _TimeSums:
 
 
 class LinearDynamicalSystems():
+    # K9's fixed-point shortcut (include/vbmp_hip.h): "auto" (outputs equal the literal recursion's to its
+    # last-bit wander), "exact" (bit for bit the literal recursion), "off" (every step runs the full recursion, as the
+    # reference does).  Per model (`m.fixed_point = "exact"`) or per call (forward_backward_loop(..., fixed_point=...)).
+    fixed_point = "auto"
+
     def __init__(self, obs_shape, hidden_dim, control_dim=0, regression_dim=0, obs_model=None,
                  latent_noise='independent', batch_shape=(), A_mask=None, B_mask=None, device=None, dtype=None):
         self.device, self.dtype = resolve(device, dtype)
@@ -365,11 +370,12 @@ class LinearDynamicalSystems():
                     for i in range(U.ndim - keep_last))
         return U[idx]
 
-    def forward_backward_loop(self, y, u, r, sums_only=False):
+    def forward_backward_loop(self, y, u, r, sums_only=False, fixed_point=None):
         """Filter + smoother for every series in one persistent kernel launch (K9).
         Returns Sigma_t_tp1, Sigma_x0_x0, mu_x0, logZ, None like the reference (:332-383) and fills self.px.
         sums_only=True (update_latents: it reads the cross terms only through their time sum and slot T-1, and logZ only through
-        its time sum): the other slots of the returned Sigma_t_tp1 are unspecified and logZ has one time step, the sum."""
+        its time sum): the other slots of the returned Sigma_t_tp1 are unspecified and logZ has one time step, the sum.
+        fixed_point: None = self.fixed_point ("auto" | "exact" | "off", see __init__)."""
         h = self.hidden_dim
         T_max = y.shape[0]
         sample_shape = tuple(y.shape[1:y.ndim - self.event_dim - self.batch_dim - 1])
@@ -385,7 +391,8 @@ class LinearDynamicalSystems():
             out = ops.lds_smoother(T_max, sample_shape, bo_shape, h, self.invQ, self.ATQA_x_x, self.QA_xp_x,
                                    self.A.ElogdetinvSigma(), x0.EinvSigma(), x0.EinvSigmamu(), x0_res,
                                    invSigma_like, invSigmamu_like.squeeze(-1), Residual_like, cu1, cu2, cu3,
-                                   sums_only=sums_only, y=y.squeeze(-1) if (sums_only and len(self.offset) == 0) else None)
+                                   sums_only=sums_only, y=y.squeeze(-1) if (sums_only and len(self.offset) == 0) else None,
+                                   fixed_point=self.fixed_point if fixed_point is None else fixed_point)
         else:
             out = self._smoother_composed(T_max, sample_shape + bo_shape, invSigma_like, invSigmamu_like.squeeze(-1),
                                           Residual_like, cu1, cu2, cu3, x0_res)

@@ -328,12 +328,15 @@ def _norm3(X, T, sample_shape, bo_shape, inner):
 
 
 def lds_smoother(T, sample_shape, bo_shape, H, invQ, ATQA_xx, QA_xp_x, A_Elogdet, x0_P, x0_eta, x0_res,
-                 like_P, like_eta, like_res, cu1, cu2, cu3, sums_only=False, y=None):
+                 like_P, like_eta, like_res, cu1, cu2, cu3, sums_only=False, y=None, fixed_point="auto"):
     """K9: one persistent launch of the information filter + smoother.
     sums_only=True (what update_latents needs): only slot T-1 of the returned Sigma_t_tp1 is meaningful (the rest is the
     sweeps' work buffer) and logZ has ONE time step holding its sum over time.
     y (observations, broadcastable to (T,)+sample+bo+(nobs,), nobs <= 16): where the device form supports it the result also
     holds "sum_mu" = sum_t mu[t] and "sum_xy" = sum_t mu[t] y[t]' (absent otherwise: the caller then uses K10).
+    fixed_point (include/vbmp_hip.h, "Fixed-point shortcut"): "auto" = stop the matrix recursions once they have converged
+    (time-independent likelihood precision only; outputs equal the literal recursion's to its last-bit wander), "exact" = only
+    at a bitwise repeat (bit for bit the literal recursion), "off" = the literal recursion at every step.
     System / prior parameters: bo_shape + (...).  Per-step operands: broadcastable to (T,)+sample+bo+(...).
     Returns dict of dense outputs shaped (T,)+sample+bo+(...) (and sample+bo+(...) for the x0 terms)."""
     dev = L.require_device(invQ, like_eta)
@@ -367,7 +370,9 @@ def lds_smoother(T, sample_shape, bo_shape, H, invQ, ATQA_xx, QA_xp_x, A_Elogdet
            "sum_xpx": torch.empty(lead[1:] + (H, H), dtype=dt, device=dev)}
     a = L.LDS_ARGS[suf]()
     a.T, a.S, a.NB, a.H = T, S, NB, H
-    a.flags = (L.LDS_CROSS_WORK | L.LDS_LOGZ_SUM) if sums_only else 0
+    if fixed_point not in L.LDS_FIXED_POINT:
+        raise ValueError(f"fixed_point must be one of {sorted(L.LDS_FIXED_POINT)}, not {fixed_point!r}")
+    a.flags = ((L.LDS_CROSS_WORK | L.LDS_LOGZ_SUM) if sums_only else 0) | L.LDS_FIXED_POINT[fixed_point]
     for name, t in zip(("invQ", "ATQA_xx", "QA_xp_x", "A_Elogdet", "x0_P", "x0_eta", "x0_res"), keep):
         setattr(a, name, t.data_ptr())
     for (name, pre), (t, st) in zip((("like_P", "lP"), ("like_eta", "le"), ("like_res", "lr"), ("cu1", "c1"),

@@ -109,6 +109,43 @@ def main():
     assert_close(d.obs_model.transition.alpha, ref.obs_model.transition.alpha, tol, what="dmbd trans alpha")
     assert_close(d.ELBO_last, ref.ELBO_last, tol, what="dmbd ELBO")
 
+    # ---- DMBD at BASELINE configs[4]'s real hyper-parameters (examples/Flocking_example.py:38 of the reference: hidden 52,
+    # 25 masked roles, regression_dim = -1): the block-form smoother at h = 52, the K = 25 role chain and the 644-entry
+    # masked solves, sharded over the series.  Inputs and initial state are the golden fixture's; its 2 series are
+    # duplicated (flipped copies, so that the ranks' slices differ) to 4.
+    cf = load_golden("dmbd_flock")["dmbd_flocking"]
+    yf = torch.cat((cf["y"], cf["y"].flip(1) * 0.95), 1).to(DEV)  # (T, 4 series, 12 birds, 4)
+
+    def flock():
+        d = DynamicMarkovBlanketDiscovery(obs_shape=(12, 4), role_dims=(1, 2, 2), hidden_dims=(4, 4, 4), regression_dim=-1,
+                                          control_dim=0, number_of_objects=6, unique_obs=False, device=DEV, dtype=torch.float64)
+        d.x0.mu = cf["init_x0_mu"].to(DEV)
+        d.A.mu = cf["init_A_mu"].to(DEV)
+        d.A.invU.gamma.alpha = cf["init_A_alpha"].to(DEV)
+        d.A.invU.gamma.beta = cf["init_A_beta"].to(DEV)
+        d.B.mu = cf["init_B_mu"].to(DEV)
+        d.obs_model.transition.alpha = cf["init_trans_alpha"].to(DEV)
+        d.obs_model.initial.alpha = cf["init_init_alpha"].to(DEV)
+        d.set_latent_parms()
+        return d
+    ref = flock()
+    assert ref.hidden_dim == 52 and ref.obs_model.transition_mask.shape == (25, 25)
+    ref.update(yf, None, None, iters=2, latent_iters=1, lr=1.0)
+    d = flock()
+    d.reducer = SuffStatReducer()
+    lo, hi = shard_bounds(yf.shape[1], rank, world)
+    d.update(yf[:, lo:hi], None, None, iters=2, latent_iters=1, lr=1.0)
+    assert d.reducer.calls == 4, d.reducer.calls
+    assert_close(d.A.mu, ref.A.mu, tol, what="flocking dmbd A mu")
+    assert_close(d.A.invU.gamma.beta, ref.A.invU.gamma.beta, tol, what="flocking dmbd A beta")
+    assert_close(d.B.mu, ref.B.mu, tol, what="flocking dmbd B mu")
+    assert_close(d.B.invU.invU, ref.B.invU.invU, tol, what="flocking dmbd B invU")
+    assert_close(d.x0.mu, ref.x0.mu, tol, what="flocking dmbd x0 mu")
+    assert_close(d.obs_model.transition.alpha, ref.obs_model.transition.alpha, tol, what="flocking dmbd trans alpha")
+    assert_close(d.ELBO_last, ref.ELBO_last, tol, what="flocking dmbd ELBO")
+    assert_close(d.px.mu, ref.px.mu[:, lo:hi], tol, what="flocking dmbd px mu (own slice)")
+    assert_close(d.obs_model.p, ref.obs_model.p[:, lo:hi], tol, what="flocking dmbd role posteriors (own slice)")
+
     # ---- batch-sharded NIW (independent posteriors): no collective, the slices tile the unsharded result
     from pyvbmp_amd.dists import NormalInverseWishart
     B, Dn = 1003, 16

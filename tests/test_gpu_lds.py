@@ -523,3 +523,107 @@ def test_lds_fixed_point_shortcut_with_a_batch_of_systems(mode, smoother_flags):
     st = olds.latent_stats(sm, yo, uo, ro, (5,), 1, 1, (NB,), 0)
     for f in ("logZ", "SE_x_xpu", "SE_y_xr"):
         assert_close(short[f], st[f], 1e-10, what=f)
+
+
+@pytest.mark.parametrize("dtype,tol,tol_modes", [(torch.float64, 1e-10, 1e-13), (torch.float32, 1e-4, 2e-6)])
+def test_lds_estep_full_size_config4_properties(dtype, tol, tol_modes):
+    """BASELINE configs[3] at FULL size -- T = 1000, 4096 series, hidden 6, Lorenz data (ref models/LinearDynamicalSystems.py:156-216,
+    332-383) -- through update_latents, in the default (fixed-point shortcut) and in the literal-recursion mode.  At this size the
+    shortcut's freeze point, the 4-deep request ring's tail and the flat-store transposition run over >= 1000 steps / 1024 waves.
+    Size-independent properties on everything (Sigma symmetric, positive definite, invSigma Sigma = I, finite evidence), the two
+    modes against each other on everything, and every 257-th series against the fp64 oracle at the north-star tolerance."""
+    from oracle import lds as olds
+    from oracle import mnw as omnw
+    from oracle import niw as oniw
+    from pyvbmp_amd import ops
+    from pyvbmp_amd.models import LinearDynamicalSystems
+    T, S, h = 1000, 4096, 6
+    y = lorenz(T, S, torch.Generator().manual_seed(40))
+    torch.manual_seed(12)
+    m = LinearDynamicalSystems((6,), h, latent_noise='shared', device=DEV, dtype=dtype)
+    yy, uu, rr = m.reshape_inputs(y.to(dtype).to(DEV))
+    sel = torch.arange(0, S, 257)
+    x0 = oniw.niw_new((h,), (), mu_init=m.x0.mu.cpu().double())
+    A = omnw.mnw_new((h, h + 1), (), mu_init=m.A.mu.cpu().double())
+    obs = omnw.mnw_new((6, h + 1), (), mu_init=m.obs_model.mu.cpu().double())
+    yo, uo, ro = olds.reshape_inputs(y[:, sel].contiguous(), None, None, (6,), 1, 1)
+    sm = olds.smoother(olds.latent_parms(A, h), x0, h, yo, uo, ro, obs, 0)
+    keep = {}
+    for mode in ("auto", "off"):
+        m.fixed_point = mode
+        m.update_latents(yy, uu, rr)
+        px = m.px
+        assert px.Sigma.shape == (T, S, h, h) and px.mu.shape == (T, S, h, 1)
+        for f in ("mu", "Sigma", "invSigma", "invSigmamu"):
+            assert bool(torch.isfinite(getattr(px, f)).all()), f"{mode}: {f} not finite"
+            assert_close(getattr(px, f)[:, sel.to(DEV)], sm[f], tol, what=f"{mode}: {f} on every 257-th series")
+        sym = float((px.Sigma - px.Sigma.transpose(-2, -1)).abs().max() / px.Sigma.abs().max())
+        assert sym <= (1e-13 if dtype == torch.float64 else 1e-5), f"{mode}: Sigma asymmetric by {sym:.2e}"
+        eye = torch.eye(h, dtype=dtype, device=DEV)
+        res = float(((px.invSigma @ px.Sigma) - eye).abs().max())
+        assert res <= (1e-9 if dtype == torch.float64 else 2e-3), f"{mode}: invSigma Sigma - I = {res:.2e}"
+        # positive definite: the product's own batched elimination (K1) counts the matrices with a non-positive pivot
+        cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
+        ops.spd_inv_logdet(px.Sigma.reshape(-1, h, h), nonspd=cnt)
+        assert int(cnt) == 0, f"{mode}: {int(cnt)} smoothed covariances are not positive definite"
+        assert bool(torch.isfinite(m.logZ).all())
+        keep[mode] = {f: getattr(px, f).clone() for f in ("mu", "Sigma")} | {f: getattr(m, f).clone() for f in ("logZ", "SE_x_x", "SE_x_xpu", "SE_xpu_xpu", "SE_x0_x0")}
+        m.px = None
+    for k in keep["auto"]:
+        assert_close(keep["auto"][k], keep["off"][k], tol_modes, what=f"shortcut against the literal recursion: {k}")
+    mid = keep["auto"]["Sigma"][T // 2 - 1:T // 2 + 2, 0]
+    assert torch.equal(mid[0], mid[1]) and torch.equal(mid[1], mid[2])  # the shortcut was taken
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 1e-4)])
+@pytest.mark.parametrize("one_minus_rate", [3e-1, 3e-2, 3e-3, 3e-4, 1e-6])
+def test_lds_fixed_point_shortcut_contraction_sweep_against_the_oracle(one_minus_rate, dtype, tol):
+    """sweep the contraction rate of the Riccati recursion (transition (1 - x) I, little process noise, weak
+    observations) from fast to near-unit-root.  The default mode may take the rounding criterion only while the recursion is
+    seen to contract (csrc/k_lds_g16.inc), so: (i) against the fp64 ORACLE every output meets the north-star tolerance or is as
+    close as the literal recursion in the same precision is (an ill-conditioned system in fp32 is ill-conditioned for both);
+    (ii) where the recursion creeps ("slow"), default == exact mode == literal recursion BIT FOR BIT."""
+    from oracle import lds as olds
+    from oracle import mnw as omnw
+    from oracle import niw as oniw
+    from pyvbmp_amd.models import LinearDynamicalSystems
+    from tests.helpers import relerr
+    T, S, h = 600, 5, 4
+    g = torch.Generator().manual_seed(21)
+    y = 0.3 * lorenz(T, S, g)[..., :3].contiguous()
+    torch.manual_seed(4)
+    m = LinearDynamicalSystems((3,), h, latent_noise='shared', device=DEV, dtype=dtype)
+    A0 = torch.cat(((1.0 - one_minus_rate) * torch.eye(h, dtype=dtype), torch.zeros(h, 1, dtype=dtype)), -1)
+    m.A.mu = A0.to(DEV).reshape(m.A.mu.shape)
+    m.obs_model.mu = (0.05 * torch.randn(m.obs_model.mu.shape, generator=g, dtype=torch.float64)).to(dtype).to(DEV)
+    qs = 1e-3
+    W = m.A.invU
+    W.invU, W.U, W.logdet_invU = W.invU * qs, W.U / qs, W.logdet_invU + h * float(torch.log(torch.tensor(qs)))
+    m.set_latent_parms()
+    outs = {}
+    for mode in ("off", "exact", "auto"):
+        m.fixed_point = mode
+        m.update_latents(*m.reshape_inputs(y.to(dtype).to(DEV)))
+        outs[mode] = {f: getattr(m.px, f).clone() for f in ("mu", "Sigma", "invSigma", "invSigmamu")} | \
+                     {f: getattr(m, f).clone() for f in ("logZ", "SE_x_x", "SE_x_xpu")}
+    x0 = oniw.niw_new((h,), (), mu_init=m.x0.mu.cpu().double())
+    A = omnw.mnw_new((h, h + 1), (), mu_init=m.A.mu.cpu().double())
+    obs = omnw.mnw_new((3, h + 1), (), mu_init=m.obs_model.mu.cpu().double())
+    A["W"] = dict(A["W"])
+    A["W"]["invU"], A["W"]["U"] = A["W"]["invU"] * qs, A["W"]["U"] / qs
+    A["W"]["logdet_invU"] = A["W"]["logdet_invU"] + h * float(torch.log(torch.tensor(qs)))
+    yo, uo, ro = olds.reshape_inputs(y, None, None, (3,), 1, 1)
+    sm = olds.smoother(olds.latent_parms(A, h), x0, h, yo, uo, ro, obs, 0)
+    st = olds.latent_stats(sm, yo, uo, ro, (3,), 1, 1, (), 0)
+    ref = {f: sm[f] for f in ("mu", "Sigma", "invSigma", "invSigmamu")} | {"logZ": st["logZ"], "SE_x_xpu": st["SE_x_xpu"]}
+    for k, r in ref.items():
+        e_auto, e_off = relerr(outs["auto"][k], r), relerr(outs["off"][k], r)
+        assert e_auto <= max(tol, 1.25 * e_off), f"{k}: default mode {e_auto:.2e} from the oracle, literal recursion {e_off:.2e}"
+        assert torch.equal(outs["exact"][k], outs["off"][k]), f"{k}: exact mode differs from the literal recursion"
+    # is the recursion still creeping in the middle of the series?  then the default must not have stopped it by tolerance
+    Sg = outs["off"]["Sigma"]
+    move = float((Sg[T // 2 + 1] - Sg[T // 2]).abs().max() / Sg[T // 2].abs().max())
+    eps = 2.2e-16 if dtype == torch.float64 else 1.2e-7
+    if move > 64 * eps:  # measurably creeping (a last-bit wander of a converged recursion stays below)
+        for k in outs["off"]:
+            assert torch.equal(outs["auto"][k], outs["off"][k]), f"{k}: stopped while the covariance still moved by {move:.1e} per step"

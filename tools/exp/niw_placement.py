@@ -8,6 +8,10 @@ from pyvbmp_amd.dists import NormalInverseWishart
 B, D, dt = 1_000_000, 16, torch.float64
 SExx, SEx, N = make_inputs(B, D, dt, "cuda")
 q = NormalInverseWishart((D,), (B,), device="cuda", dtype=dt)
+if len(sys.argv) > 1:  # grid cap in blocks per CU (0 = the library default)
+    import ctypes
+    _l = _lib.load(); _l.vbmp_debug_set_blocks_per_cu.argtypes = [ctypes.c_int]; _l.vbmp_debug_set_blocks_per_cu(int(sys.argv[1]))
+    print("grid cap", sys.argv[1])
 
 
 def _r():
