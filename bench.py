@@ -359,9 +359,12 @@ class DmbdWorkload:
         self.bytes_per_launch = self.bpu * self.units
         self.launches_per_step = 1
         self.iterations = 0
+        if self.a.graphed and self.reducer is None:  # capture outside the timed region (2 eager warm-up iterations + 1 replay)
+            m.update(self.y, None, None, iters=3, latent_iters=1, lr=self.a.dmbd_lr, graphed=True)
 
     def step(self):
-        self.m.update(self.y, None, None, iters=1, latent_iters=1, lr=self.a.dmbd_lr)
+        # --graphed: the iteration replayed as one HIP graph (single rank only: the collectives are not captured)
+        self.m.update(self.y, None, None, iters=1, latent_iters=1, lr=self.a.dmbd_lr, graphed=self.a.graphed and self.reducer is None)
         self.iterations += 1
 
     def config(self, world, scaling):
@@ -373,6 +376,7 @@ class DmbdWorkload:
                "T": self.T, "series": self.total, "series_is": per, "hidden": self.h, "roles": 25,
                "parallelism": f"series-sharded x{world}",
                "collectives_per_iteration": (self.reducer.calls / max(self.iterations, 1)) if self.reducer is not None else 0,
+               "graphed": bool(self.a.graphed and self.reducer is None),
                "elbo_finite": bool(torch.isfinite(self.m.ELBO_last).all())}
         return cfg
 
@@ -384,7 +388,40 @@ class DmbdWorkload:
         return f"dmbd_{self.dtype_name}_T{self.T}_S{self.S}"
 
     def cpu_baseline(self, target_s=10.0):
-        return None  # no CPU restatement of the whole DMBD iteration exists; BASELINE.md quotes the reference's own timing
+        """No CPU restatement of the WHOLE DMBD iteration exists (parity rests on goldens generated from the reference), so the
+        headline value here is the reference's own timing as BASELINE.md 2 records it (survey container, 8 threads; it cannot
+        travel to this host), and next to it the oracle's port of the iteration's dominant part -- the information filter /
+        smoother at hidden 52 with one likelihood precision per (t, series) (models/LinearDynamicalSystems.py:268-383 of the
+        reference) -- is timed on this host's cores on a bounded sample."""
+        from oracle import lds as olds
+        from oracle import mnw as omnw
+        from oracle import niw as oniw
+        h, T = self.h, self.T
+        g = torch.Generator().manual_seed(5)
+        x0 = oniw.niw_new((h,), (), mu_init=0.1 * torch.randn(h, generator=g, dtype=torch.float64))
+        A = omnw.mnw_new((h, h + 1), (), mu_init=0.05 * torch.randn(h, h + 1, generator=g, dtype=torch.float64))
+        lp = olds.latent_parms(A, h)
+
+        def run(Sc):
+            Wm = 0.2 * torch.randn(T, Sc, h, 8, generator=g, dtype=torch.float64)
+            P = Wm @ Wm.transpose(-2, -1) + 0.5 * torch.eye(h, dtype=torch.float64)
+            eta = torch.randn(T, Sc, h, 1, generator=g, dtype=torch.float64)
+            res = torch.randn(T, Sc, generator=g, dtype=torch.float64)
+            yo, uo, ro = olds.reshape_inputs(torch.zeros(T, Sc, 1, dtype=torch.float64), None, None, (1,), 1, 1)
+            t0 = time.perf_counter()
+            olds.smoother(lp, x0, h, yo, uo, ro, None, 0, like=(P, eta, res))
+            return time.perf_counter() - t0
+        t_small = run(2)
+        Sc = int(min(20, max(2, 2 * target_s / 2.0 / max(t_small, 1e-3))))
+        best = run(Sc)
+        ref_s = (1.05, 3.8)  # BASELINE.md 2: DynamicMarkovBlanketDiscovery.update, Flocking hyper-parameters, (30, 4, 12, 4) fp32
+        return {"value": 30 * 4 / ref_s[0], "unit": self.unit, "cores": 8,
+                "kind": "reference (quoted from BASELINE.md 2: survey container, 8 threads; not re-timed on this host)",
+                "sample": f"DynamicMarkovBlanketDiscovery.update of the imported reference at these hyper-parameters on (T=30, 4 series, 12 "
+                          f"observables) fp32: {ref_s[0]}-{ref_s[1]} s per iteration, best case quoted",
+                "port_smoother": {"value": T * Sc / best, "unit": self.unit, "cores": torch.get_num_threads(), "kind": "port",
+                                  "sample": f"oracle.lds.smoother (fp64) at hidden {h}, one likelihood precision per (t, series), T={T}, {Sc} "
+                                            f"series: {best:.2f} s -- the smoother alone, not the iteration; host has {os.cpu_count()} logical cpus"}}
 
 
 def make_workload(args):
@@ -444,6 +481,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--oversubscribe", action="store_true", help="rehearsal on a box with fewer GPUs than ranks: ranks share "
                     "the cards round-robin (use with --backend gloo; RCCL wants one GPU per rank); never for reported numbers")
+    ap.add_argument("--graphed", action="store_true", help="dmbd: replay the VB iteration as one HIP graph (pyvbmp_amd.graph)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strong", action="store_true", dest="no_strong", help="N > 1: skip the extra strong-scaling pass")
     args = ap.parse_args()
@@ -518,8 +556,21 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     _lib.launch_hooks = None
-    assert len(starts) == len(stops) == args.steps * wl.launches_per_step, \
-        f"{wl.launches_per_step} launch(es) of {wl.kernel} per step expected, saw {len(starts)} in {args.steps} steps"
+    kernel_ms_source = "HIP events around each launch inside the timed region"
+    if args.graphed and args.workload == "dmbd" and world == 1 and not starts:
+        # a graph replay launches nothing from Python, so no hook fires: the dominant kernel's duration is measured on three
+        # eager iterations AFTER (and outside) the timed region -- same kernel, same shapes, same state
+        args.graphed = False
+        _lib.launch_hooks = (before, after)
+        for _ in range(3):
+            wl.step()
+        torch.cuda.synchronize()
+        _lib.launch_hooks = None
+        args.graphed = True
+        kernel_ms_source = "HIP events around 3 eager launches after the timed region (graph replays have no launch hook)"
+    else:
+        assert len(starts) == len(stops) == args.steps * wl.launches_per_step, \
+            f"{wl.launches_per_step} launch(es) of {wl.kernel} per step expected, saw {len(starts)} in {args.steps} steps"
     kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, stops)) / len(starts)
     units_total = wl.units
     if dist is not None:
@@ -567,7 +618,7 @@ def main():
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "traffic_key": wl.traffic_key(),
-                "kernel": wl.kernel_dev, "kernel_ms": kernel_ms}
+                "kernel": wl.kernel_dev, "kernel_ms": kernel_ms, "kernel_ms_source": kernel_ms_source}
         roof.update(wl.roofline_extra())
         if "flop_per_message" in roof:
             tf = roof["flop_per_message"] * wl.units / (kernel_ms * 1e-3) / 1e12

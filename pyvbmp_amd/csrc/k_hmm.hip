@@ -67,18 +67,23 @@ __device__ __forceinline__ T lse_lanes(T mine) {
   return m + log(grp_sum<Kp>(mine > neg_inf<T>() ? exp(mine - m) : T(0)));
 }
 
-// smallest column sum the probability-space step accepts (see k_hmm_fb): terms within 1e-17 of it are still normal
-template <typename T> __device__ __forceinline__ T hmm_safe_sum();
-template <> __device__ __forceinline__ double hmm_safe_sum<double>() { return 1e-130; }
-template <> __device__ __forceinline__ float hmm_safe_sum<float>() { return 1e-25f; }
+// smallest exp(transition) the probability-space step accepts as a factor (below it the product a_i A_ij would lose bits)
+template <typename T> __device__ __forceinline__ T hmm_tiny();
+template <> __device__ __forceinline__ double hmm_tiny<double>() { return 1e-290; }
+template <> __device__ __forceinline__ float hmm_tiny<float>() { return 1e-30f; }
 
 // Every step needs, for each target state j, L_j = log sum_i exp(x_i + tr_ij) over the K source states.  Taken
 // literally that is K exponentials per lane and step (K^2 per chain), which was ~90 % of this kernel in fp64.  Here a
-// step factors the sum as  exp(M) * sum_i a_i A_ij  with M = max_i x_i, a_i = exp(x_i - M) (ONE exponential per lane,
-// exchanged through LDS) and A = exp(tr) kept in registers, i.e. the scaled probability-space recursion -- but only
-// when that is exact to rounding: every column sum s_j must be >= hmm_safe_sum (then all terms that matter are
-// normal numbers) or exactly zero with no reachable source state.  A chain that fails the test in some step (logit
-// spreads of hundreds combined with forbidden transitions) takes the literal log-space form for that step.
+// step factors the sum in probability space with A = exp(tr) kept in registers and ONE exponential per lane -- in an
+// EXTENDED-RANGE form, so that it survives sharp posteriors (round 3; round 2's form scaled by one exp(M) per chain and
+// fell back to the literal step whenever the sources that reach some column all sat > 300 decades below the chain's
+// maximum, which after the first DMBD iteration was most steps): with M = max_i x_i,
+//     exp(x_i - M) = f_i 2^{n_i},   n_i = floor((x_i - M) log2 e) (an integer, however negative),  f_i = exp((x_i - M) - n_i ln 2) in [1, 2)
+// (ln 2 split in two parts so that the reduction is exact to rounding), exchanged through LDS as (f_i, n_i); column j takes
+// its OWN reference exponent E_j = max {n_i : A_ij > 0} and sums s_j = sum_i ldexp(f_i, n_i - E_j) A_ij, whose largest term
+// is >= A_ij -- no underflow that matters, terms 2^-1000 below the column's largest flush to zero exactly as exp() does in
+// the literal form -- and L_j = M + E_j ln 2 + log s_j.  The literal log-space step remains for chains whose transition
+// matrix itself underflows (0 < exp(tr_ij) < 1e-290 / 1e-30).
 template <typename T, int Kp>
 __global__ __launch_bounds__(64) void k_hmm_fb(const T* __restrict__ logits, const T* __restrict__ trans,
                                                const T* __restrict__ init, int64_t Tn, int64_t C, int64_t NB, int K,
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(64) void k_hmm_fb(const T* __restrict__ logits, con
   const int64_t cc = c < C ? c : C - 1;
   const int64_t b = cc % NB;
   constexpr int LDM = Kp + 1;  // odd row stride: lane j reads ROW j of the pair matrix, a stride of Kp words would put all lanes on one bank
-  T* vec = smem + cl * (Kp + Kp * LDM);  // [Kp] message exchange, [Kp][LDM] pair weights
+  T* vec = smem + cl * (Kp + Kp * LDM + Kp);  // [Kp] message exchange, [Kp][LDM] pair weights, [Kp] exponents
   T* mat = vec + Kp;
   const T NI = neg_inf<T>();
   // column j of the transition matrix (A = exp(log transition); the log form is re-read from global memory by the rare
@@ -108,26 +113,61 @@ __global__ __launch_bounds__(64) void k_hmm_fb(const T* __restrict__ logits, con
   // do all lanes of my chain agree?
   const unsigned long long grp = (Kp == 64) ? ~0ull : (((1ull << (Kp & 63)) - 1ull) << (cl * Kp));
   auto chain_all = [&](bool ok) -> bool { return (__ballot(ok) & grp) == grp; };
-  // Column sums in probability space for the message x (entry j on lane j; lanes j >= K pass -inf).  Leaves a_i in
-  // vec[0..Kp) and returns M, s_j and whether the whole chain may use them.
-  auto col_sums = [&](T x, T& M, T& sj) -> bool {
+  // does exp(tr) represent every finite transition of my chain's matrix?  (wave-level vote per chain, once)
+  bool a_ok = true;
+#pragma unroll
+  for (int i = 0; i < Kp; ++i) a_ok = a_ok && !(TR(i) > NI && !(A[i] >= hmm_tiny<T>()));
+  const bool prob_space = chain_all(a_ok);
+  int* vecn = reinterpret_cast<int*>(vec + Kp + Kp * LDM);  // [Kp] exponents n_i
+  constexpr int NEG = -(1 << 29);
+  // Column sums in extended-range probability space for the message x (entry j on lane j; lanes j >= K pass -inf).
+  // Leaves (f_i, n_i) in vec / vecn and returns M, E_j (as a multiple of ln 2 in `Eln`, and raw in `Ej`) and s_j.
+  auto col_sums = [&](T x, T& M, int& Ej, T& sj) {
     M = grp_max<Kp>(x);
-    const T aj = (x > NI) ? exp(x - M) : T(0);
+    const bool fin = x > NI;  // (M > -inf whenever some x is)
+    const T d = fin ? x - M : T(0);
+    T nf = floor(d * T(1.4426950408889634073599246810019));
+    nf = nf < T(NEG) ? T(NEG) : nf;
+    // d - n ln2 with ln2 = hi + lo, hi holding 32 (fp64) / 12 (fp32) significant bits: n * hi is exact for |n| < 2^20 / 2^11;
+    // beyond that the term is 2^-2048 below the maximum and its mantissa does not matter
+    T r;
+    if constexpr (sizeof(T) == 8) {
+      r = __builtin_fma(-nf, T(6.93147180369123816490e-01), d);
+      r = __builtin_fma(-nf, T(1.90821492927058770002e-10), r);
+    } else {
+      r = __builtin_fmaf(-nf, T(6.9314575195e-01f), d);
+      r = __builtin_fmaf(-nf, T(1.4286067653e-06f), r);
+    }
+    const T fj = fin ? exp(r) : T(0);
+    const int nj = fin ? (int)nf : NEG;
     wsync();  // the previous readers of vec are done
-    vec[j] = aj;
+    vec[j] = fj;
+    vecn[j] = nj;
     wsync();
+    int E = NEG;
+#pragma unroll
+    for (int i = 0; i < Kp; ++i) {
+      const int ni = vecn[i];
+      E = (A[i] > T(0) && ni > E) ? ni : E;  // (padding sources carry NEG, forbidden ones A = 0)
+    }
     sj = T(0);
 #pragma unroll
-    for (int i = 0; i < Kp; ++i) sj += vec[i] * A[i];  // entries i >= K are 0 * 0: no guard, the reads go out together
-    const bool lost = !chain_all(!(x > NI && aj == T(0)));  // some finite entry of x underflowed against M
-    bool ok = sj >= hmm_safe_sum<T>() || j >= K;  // padding lanes never vote (and never walk the loop below)
-    if (!ok && sj == T(0)) {  // exact if no source state reaches j at all
-      bool reach = false;
-      for (int i = 0; i < K; ++i) reach = reach || (vec[i] > T(0) && TR(i) > NI);
-      ok = !reach && !lost;
+    for (int i = 0; i < Kp; ++i) {
+      int sh = vecn[i] - E;            // <= 0 for every source that reaches j; anything for the others (their A is 0)
+      sh = sh > 0 ? 0 : sh;
+      sh = sh < -2100 ? -2100 : sh;    // ldexp flushes to zero far before
+      sj += ldexp(vec[i], sh) * A[i];
     }
-    return chain_all(ok);
+    Ej = E;
   };
+  // w_i = a_i A_ij / 2^{E_j} for the pair weights of the backward step (same terms as in s_j)
+  auto col_term = [&](int i, int Ej) -> T {
+    int sh = vecn[i] - Ej;
+    sh = sh > 0 ? 0 : sh;
+    sh = sh < -2100 ? -2100 : sh;
+    return ldexp(vec[i], sh) * A[i];
+  };
+  const T LN2 = T(0.693147180559945309417232121458);
   const T in_j = (j < K) ? init[b * K + j] : NI;
   const T* lg = logits + cc * K + (j < K ? j : 0);  // element (t, c, j) at lg[t*C*K]
   T* pj = p + cc * K + (j < K ? j : 0);
@@ -141,9 +181,11 @@ __global__ __launch_bounds__(64) void k_hmm_fb(const T* __restrict__ logits, con
   for (int64_t t = 0; t < Tn; ++t) {
     const T lg_t = lg_next;
     lg_next = lg[(t + 1 < Tn ? t + 1 : t) * ts];
-    T M, sj;
-    if (col_sums(prev, M, sj)) {
-      prev = ((sj > T(0)) ? M + log(sj) : NI) + (j < K ? lg_t : T(0));
+    if (prob_space) {
+      T M, sj;
+      int Ej;
+      col_sums(prev, M, Ej, sj);
+      prev = ((sj > T(0)) ? (M + T(Ej) * LN2) + log(sj) : NI) + (j < K ? lg_t : T(0));
     } else {
       // literal log-space step
       wsync();
@@ -188,13 +230,16 @@ __global__ __launch_bounds__(64) void k_hmm_fb(const T* __restrict__ logits, con
     // column j of the pair logits: xi[i][j] = (src[i] + tr[i][j] - lse_i(src[i] + tr[i][j])) + nxt[j]; the step needs
     // e_ij = exp(xi_ij - Gs) for some common Gs: row sums of e give the new message, their total the normaliser,
     // e / total the pair posterior (the reference's three log-sum-exps over the same K x K logits, :88-95).
-    T e[Kp], Gs, M, sj;
-    if (col_sums(xs, M, sj)) {
-      // probability space: exp(src_i + tr_ij - lse) = a_i A_ij / s_j, and Gs = max_j nxt_j keeps every e_ij <= 1
+    T e[Kp], Gs;
+    if (prob_space) {
+      // probability space: exp(src_i + tr_ij - lse) = a_i A_ij / (2^{E_j} s_j), and Gs = max_j nxt_j keeps every e_ij <= 1
+      T M, sj;
+      int Ej;
+      col_sums(xs, M, Ej, sj);
       Gs = nxt_max;
       const T u = (j < K && nxt > NI && sj > T(0)) ? exp(nxt - Gs) / sj : T(0);
 #pragma unroll
-      for (int i = 0; i < Kp; ++i) e[i] = (vec[i] * A[i]) * u;
+      for (int i = 0; i < Kp; ++i) e[i] = col_term(i, Ej) * u;
     } else {
       // literal log-space step, ONE exponentiation per pair with Gs the largest pair logit
       wsync();
@@ -263,7 +308,7 @@ static int launch_hmm(const T* logits, const T* trans, const T* init, int64_t Tn
                       T* p, T* SEzz, T* SEz0, T* logZ, hipStream_t st) {
   constexpr int CPW = 64 / Kp;
   const int64_t blocks = (C + CPW - 1) / CPW;
-  const size_t smem = (size_t)CPW * (Kp + Kp * (Kp + 1)) * sizeof(T);
+  const size_t smem = (size_t)CPW * (Kp + Kp * (Kp + 1) + Kp) * sizeof(T);  // message, pair weights, exponents (int, in T-sized slots)
   hipLaunchKernelGGL((k_hmm_fb<T, Kp>), dim3((unsigned)blocks), dim3(64), smem, st, logits, trans, init, Tn, C, NB, K,
                      ptemp, p, SEzz, SEz0, logZ);
   return hipGetLastError() == hipSuccess ? 0 : VBMP_ERR_LAUNCH;

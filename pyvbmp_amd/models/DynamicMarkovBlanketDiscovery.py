@@ -159,11 +159,18 @@ class DynamicMarkovBlanketDiscovery(LinearDynamicalSystems):
             self.update_latents(y, u, r)
         return self.logZ - (self.obs_model.p * (self.obs_model.p + 1e-8).log()).sum(0).sum((-1, -2))
 
-    def update(self, y, u, r, iters=1, latent_iters=1, lr=1.0, verbose=False):
-        """VB iterations (ref models/DynamicMarkovBlanketDiscovery.py:185-211).  No HIP-graph option here: an iteration
-        at the reference's flocking sizes is ~10^4 launches and replaying it as one graph measured SLOWER than the eager
-        loop on this ROCm (86.9 vs 63.4 ms; the iteration itself is free of host synchronisations, so the CPU already
-        runs ahead at the runtime's launch rate)."""
+    def update(self, y, u, r, iters=1, latent_iters=1, lr=1.0, verbose=False, graphed=False):
+        """VB iterations (ref models/DynamicMarkovBlanketDiscovery.py:185-211).  graphed=True replays the iteration as ONE HIP
+        graph (pyvbmp_amd.graph): at the reference's flocking sizes an iteration is ~470 launches, a third of its time their
+        launch cost.  (Round 1 found the replay slower than the eager loop -- 86.9 vs 63.4 ms -- when an iteration still was
+        ~10^4 launches.)  Not with verbose (printing synchronises), a multi-rank reducer (the collective is not captured) or
+        latent_iters > 1 (the posterior is re-created inside the iteration)."""
+        if graphed and not verbose and latent_iters == 1 and (self.reducer is None or self.reducer.world_size == 1):
+            from .. import graph
+            key = tuple((t.data_ptr(), tuple(t.shape), t.dtype) if t is not None else None for t in (y, u, r)) + (float(lr),)
+            graph.run_iterations(self, lambda m: m._vb_iteration(*m.reshape_inputs(y, u, r), 1, lr), iters, key,
+                                 post=lambda m: m._after_iteration())
+            return
         y, u, r = self.reshape_inputs(y, u, r)
         for i in range(iters):
             t = time.time()

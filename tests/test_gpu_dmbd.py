@@ -107,6 +107,47 @@ def test_dmbd_flocking_hyperparameters_golden(golden):
         assert_close(m.obs_model.transition.alpha, c[pre + "trans_alpha"], tol, what=pre + "trans alpha")
 
 
+@pytest.mark.parametrize("which", ["lorenz_like", "flocking"])
+def test_dmbd_graphed_update_matches_eager(golden, which):
+    """DynamicMarkovBlanketDiscovery.update(..., graphed=True): the VB iteration replayed as ONE HIP graph (pyvbmp_amd.graph)
+    against the eager loop -- same state after 5 iterations (atomics reorder the sums: 1e-8), at the Lorenz-like and at the
+    flocking hyper-parameters (hidden 52, 25 roles: block-form smoother, masked solves and the role chain inside the capture)."""
+    from pyvbmp_amd.models import DynamicMarkovBlanketDiscovery
+    if which == "flocking":
+        c = golden("dmbd_flock")["dmbd_flocking"]
+        kw = dict(obs_shape=(12, 4), role_dims=(1, 2, 2), hidden_dims=(4, 4, 4), regression_dim=-1, control_dim=0,
+                  number_of_objects=6, unique_obs=False)
+    else:
+        c = golden("dmbd")["dmbd_lorenz_like"]
+        kw = dict(obs_shape=(int(c["n_obs"]), int(c["obs_dim"])), role_dims=tuple(int(v) for v in c["role_dims"]),
+                  hidden_dims=tuple(int(v) for v in c["hidden_dims"]), regression_dim=0, control_dim=0,
+                  number_of_objects=int(c["number_of_objects"]))
+    y = c["y"].to(DEV)
+    out = []
+    for graphed in (False, True):
+        m = DynamicMarkovBlanketDiscovery(device=DEV, dtype=torch.float64, **kw)
+        m.x0.mu = c["init_x0_mu"].to(DEV)
+        m.A.mu = c["init_A_mu"].to(DEV)
+        m.A.invU.gamma.alpha = c["init_A_alpha"].to(DEV)
+        m.A.invU.gamma.beta = c["init_A_beta"].to(DEV)
+        m.B.mu = c["init_B_mu"].to(DEV)
+        m.obs_model.transition.alpha = c["init_trans_alpha"].to(DEV)
+        m.obs_model.initial.alpha = c["init_init_alpha"].to(DEV)
+        m.set_latent_parms()
+        m.update(y, None, None, iters=3, latent_iters=1, lr=1.0, graphed=graphed)
+        m.update(y, None, None, iters=2, latent_iters=1, lr=1.0, graphed=graphed)  # a second call reuses the cached graph
+        out.append(m)
+    a, b = out
+    assert b.iters == a.iters == 5 and b.ELBO_save.shape == a.ELBO_save.shape
+    tol = 1e-8
+    assert_close(b.ELBO_save[1:], a.ELBO_save[1:], tol, what="ELBO trace")
+    assert_close(b.px.mu, a.px.mu, tol, what="px mu")
+    assert_close(b.obs_model.p, a.obs_model.p, tol, what="role posteriors")
+    assert_close(b.A.mu, a.A.mu, tol, what="A mu")
+    assert_close(b.B.invU.invU, a.B.invU.invU, tol, what="B invU")
+    assert_close(b.obs_model.transition.alpha, a.obs_model.transition.alpha, tol, what="transition alpha")
+
+
 class _PairReducer:
     """two 'ranks' (threads on one GPU) with a barrier standing in for the all-reduce"""
 

@@ -620,10 +620,18 @@ def test_lds_fixed_point_shortcut_contraction_sweep_against_the_oracle(one_minus
         e_auto, e_off = relerr(outs["auto"][k], r), relerr(outs["off"][k], r)
         assert e_auto <= max(tol, 1.25 * e_off), f"{k}: default mode {e_auto:.2e} from the oracle, literal recursion {e_off:.2e}"
         assert torch.equal(outs["exact"][k], outs["off"][k]), f"{k}: exact mode differs from the literal recursion"
-    # is the recursion still creeping in the middle of the series?  then the default must not have stopped it by tolerance
+    # The default against the literal recursion.  `move` is what the literal recursion's smoothed covariance still does per step in
+    # the middle of the series: a last-bit wander where it has converged, rounding noise of the information-form update where the
+    # process noise is small (the update subtracts terms ~1 / qs: ~1e3 ulp here), or a genuine creep.  A recursion stopped while it
+    # creeps at rate r sits move / (1 - r) from the literal one -- far beyond the bound below for the slow systems of this sweep.
     Sg = outs["off"]["Sigma"]
     move = float((Sg[T // 2 + 1] - Sg[T // 2]).abs().max() / Sg[T // 2].abs().max())
     eps = 2.2e-16 if dtype == torch.float64 else 1.2e-7
-    if move > 64 * eps:  # measurably creeping (a last-bit wander of a converged recursion stays below)
+    diffs = {k: relerr(outs["auto"][k], outs["off"][k]) for k in outs["off"]}
+    print(f"1 - rate = {one_minus_rate:g}: literal recursion moves {move:.1e} per step at T / 2; default against literal:",
+          {k: f"{v:.1e}" for k, v in diffs.items()})
+    for k, v in diffs.items():
+        assert v <= max(64 * eps, 16 * move), f"{k}: default mode {v:.2e} from the literal recursion, which moves {move:.1e} per step"
+    if one_minus_rate <= 3e-4 and move > 64 * eps:  # the near-unit-root systems creep for the whole series: nothing may stop them
         for k in outs["off"]:
             assert torch.equal(outs["auto"][k], outs["off"][k]), f"{k}: stopped while the covariance still moved by {move:.1e} per step"
