@@ -121,8 +121,8 @@ __global__ __launch_bounds__(64) void k_hmm_fb(const T* __restrict__ logits, con
   int* vecn = reinterpret_cast<int*>(vec + Kp + Kp * LDM);  // [Kp] exponents n_i
   constexpr int NEG = -(1 << 29);
   // Column sums in extended-range probability space for the message x (entry j on lane j; lanes j >= K pass -inf).
-  // Leaves (f_i, n_i) in vec / vecn and returns M, E_j (as a multiple of ln 2 in `Eln`, and raw in `Ej`) and s_j.
-  auto col_sums = [&](T x, T& M, int& Ej, T& sj) {
+  // Leaves (f_i, n_i) in vec / vecn and returns M, E_j, s_j and (w != nullptr) the terms w_i = f_i 2^{n_i - E_j} A_ij of s_j.
+  auto col_sums = [&](T x, T& M, int& Ej, T& sj, T* w) {
     M = grp_max<Kp>(x);
     const bool fin = x > NI;  // (M > -inf whenever some x is)
     const T d = fin ? x - M : T(0);
@@ -144,28 +144,22 @@ __global__ __launch_bounds__(64) void k_hmm_fb(const T* __restrict__ logits, con
     vec[j] = fj;
     vecn[j] = nj;
     wsync();
-    int E = NEG;
+    int nn[Kp], E = NEG;
 #pragma unroll
     for (int i = 0; i < Kp; ++i) {
-      const int ni = vecn[i];
-      E = (A[i] > T(0) && ni > E) ? ni : E;  // (padding sources carry NEG, forbidden ones A = 0)
+      nn[i] = vecn[i];
+      E = (A[i] > T(0) && nn[i] > E) ? nn[i] : E;  // (padding sources carry NEG, forbidden ones A = 0)
     }
     sj = T(0);
 #pragma unroll
     for (int i = 0; i < Kp; ++i) {
-      int sh = vecn[i] - E;            // <= 0 for every source that reaches j; anything for the others (their A is 0)
-      sh = sh > 0 ? 0 : sh;
-      sh = sh < -2100 ? -2100 : sh;    // ldexp flushes to zero far before
-      sj += ldexp(vec[i], sh) * A[i];
+      // shift <= 0 for every source that reaches j; the others may sit above E, but their A is 0 (v_ldexp takes any int)
+      const int sh = nn[i] - E;
+      const T wi = ldexp(vec[i], sh > 0 ? 0 : sh) * A[i];
+      if (w) w[i] = wi;  // (compile-time: the pair weights of the backward step reuse the terms)
+      sj += wi;
     }
     Ej = E;
-  };
-  // w_i = a_i A_ij / 2^{E_j} for the pair weights of the backward step (same terms as in s_j)
-  auto col_term = [&](int i, int Ej) -> T {
-    int sh = vecn[i] - Ej;
-    sh = sh > 0 ? 0 : sh;
-    sh = sh < -2100 ? -2100 : sh;
-    return ldexp(vec[i], sh) * A[i];
   };
   const T LN2 = T(0.693147180559945309417232121458);
   const T in_j = (j < K) ? init[b * K + j] : NI;
@@ -184,7 +178,7 @@ __global__ __launch_bounds__(64) void k_hmm_fb(const T* __restrict__ logits, con
     if (prob_space) {
       T M, sj;
       int Ej;
-      col_sums(prev, M, Ej, sj);
+      col_sums(prev, M, Ej, sj, nullptr);
       prev = ((sj > T(0)) ? (M + T(Ej) * LN2) + log(sj) : NI) + (j < K ? lg_t : T(0));
     } else {
       // literal log-space step
@@ -235,11 +229,11 @@ __global__ __launch_bounds__(64) void k_hmm_fb(const T* __restrict__ logits, con
       // probability space: exp(src_i + tr_ij - lse) = a_i A_ij / (2^{E_j} s_j), and Gs = max_j nxt_j keeps every e_ij <= 1
       T M, sj;
       int Ej;
-      col_sums(xs, M, Ej, sj);
+      col_sums(xs, M, Ej, sj, e);
       Gs = nxt_max;
       const T u = (j < K && nxt > NI && sj > T(0)) ? exp(nxt - Gs) / sj : T(0);
 #pragma unroll
-      for (int i = 0; i < Kp; ++i) e[i] = col_term(i, Ej) * u;
+      for (int i = 0; i < Kp; ++i) e[i] *= u;
     } else {
       // literal log-space step, ONE exponentiation per pair with Gs the largest pair logit
       wsync();

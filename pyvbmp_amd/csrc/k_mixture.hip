@@ -4,6 +4,7 @@
 #include "vbmp_dispatch.h"
 #include "../../include/vbmp_hip.h"
 
+#include "vbmp_flags.h"
 extern "C" int g_vbmp_flags;
 extern "C" int g_vbmp_blocks_per_cu;
 
@@ -884,7 +885,7 @@ static bool quadform_mfma_launch(const T* X, int64_t S, int64_t Bo, int64_t Bi, 
   const dim3 g((unsigned)gx, (unsigned)Bi, (unsigned)nz), blk(256);
   const size_t smem = per * BC;
   if (fused) *fused = false;
-  if (NA && logZ && Bi == 1 && nz == 1 && Bo <= 32 && !(g_vbmp_flags & 0x4000)) {  // 0x4000: two-kernel form (A/B, tests)
+  if (NA && logZ && Bi == 1 && nz == 1 && Bo <= 32 && !(g_vbmp_flags & VBMP_DBG_ESTEP_2KERNEL)) {  // debug flag: two-kernel form (A/B, tests)
     const int KG = Bo <= 4 ? 1 : Bo <= 8 ? 2 : Bo <= 16 ? 4 : 8;
 #define VBMP_QFF(DTV, KGV) \
   hipLaunchKernelGGL((k_quadform_mfma<T, DTV, KGV>), g, blk, smem, st, X, S, Bo, Bi, D, P, b, c, out, BC, tpb, NA, logZ)
@@ -908,7 +909,7 @@ static int quadform_dispatch(const T* X, int64_t S, int64_t Bo, int64_t Bi, int 
   if (S == 0 || Bo == 0 || Bi == 0) return 0;
   if (!X || !P || !b || !c || !out || S < 0 || Bo < 0 || Bi < 0 || D < 1 || D > VBMP_MAX_DIM) return VBMP_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (!(g_vbmp_flags & 0x100) && quadform_mfma_launch<T>(X, S, Bo, Bi, D, P, b, c, out, st))  // 0x100: VALU form only
+  if (!(g_vbmp_flags & VBMP_DBG_QF_VALU) && quadform_mfma_launch<T>(X, S, Bo, Bi, D, P, b, c, out, st))  // debug flag: VALU form only
     return hipGetLastError() == hipSuccess ? 0 : VBMP_ERR_LAUNCH;
   const int64_t blocks = (S * Bi + 255) / 256;
   VBMP_DISPATCH_DIM(T, D, {
@@ -934,7 +935,7 @@ static int estep_dispatch(const T* X, int64_t S, int K, int D, const T* P, const
   // D >= 8: log-likelihoods on the matrix cores into the p buffer, then the in-place softmax pass
   const size_t sm_smem = (size_t)512 * (K + 1) * sizeof(T);  // rows of a chunk + per-thread running sums
   bool fused = false;
-  if (!(g_vbmp_flags & 0x100) && sm_smem <= 150 * 1024 && quadform_mfma_launch<T>(X, S, K, 1, D, P, b, c, p, st, NA, logZ, &fused)) {
+  if (!(g_vbmp_flags & VBMP_DBG_QF_VALU) && sm_smem <= 150 * 1024 && quadform_mfma_launch<T>(X, S, K, 1, D, P, b, c, p, st, NA, logZ, &fused)) {
     if (fused) return hipGetLastError() == hipSuccess ? 0 : VBMP_ERR_LAUNCH;  // p, NA, logZ are complete
     if (sm_smem > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_estep_softmax<T>), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -42,11 +42,10 @@ class SuffStatReducer():
 
     The buffer is persistent: it is laid out once per exchange signature (shapes, dtype, device of the statistics -- an
     exchange of a VB iteration has the same signature every iteration) and reused, so that an iteration neither
-    concatenates nor splits fresh tensors.  The statistics are written into their slots with one multi-tensor copy, the
-    flat buffer is reduced in place, and the returned tensors are the slots themselves: they stay valid until the next
-    exchange with the same signature (callers rebind their attributes every iteration, as the reference's classes do).
+    concatenates nor splits the statistics.  They are written into their slots with one multi-tensor copy, the flat buffer
+    is reduced in place, and the results are handed back as views of ONE clone of it (fresh memory: the caller may keep them).
     `slots(...)` hands the slot views out beforehand for producers that can write their result straight into the
-    packed buffer."""
+    packed buffer; statistics passed back as those very views are returned in place (valid until the next exchange)."""
 
     def __init__(self, group=None):
         self.group = group
@@ -69,6 +68,10 @@ class SuffStatReducer():
         return list(self._buffer(shapes, dtype, device).views)
 
     def all_reduce(self, tensors):
+        """sum of every tensor over the group, ONE collective.  Returns fresh tensors (views of one clone of the packed buffer),
+        so a result kept across iterations -- or passed to a second model that shares this reducer -- is never overwritten by the
+        next exchange of the same signature.  Zero-copy only for inputs that ARE this signature's slot views (`slots()`): those
+        come back as the slots themselves, valid until the next exchange."""
         tensors = [t if isinstance(t, torch.Tensor) else torch.as_tensor(t) for t in tensors]
         if not dist.is_initialized() or self.world_size == 1:
             return list(tensors)
@@ -76,9 +79,23 @@ class SuffStatReducer():
         for t in tensors:
             dt = torch.promote_types(dt, t.dtype)
         pk = self._buffer([t.shape for t in tensors], dt, tensors[0].device)
-        todo = [(v, t) for v, t in zip(pk.views, tensors) if t.data_ptr() != v.data_ptr() or t.dtype != dt]
+        own = [t.dtype == dt and t.data_ptr() == v.data_ptr() and t.shape == v.shape and t.stride() == v.stride()
+               for v, t in zip(pk.views, tensors)]
+        # an input that lives inside the packed buffer at ANOTHER position (a slot view passed back in a different place) would
+        # be clobbered by the copies of the slots before it: take it out first
+        store = pk.flat.untyped_storage().data_ptr()
+        tensors = [t.clone() if (not o and t.numel() > 0 and t.untyped_storage().data_ptr() == store) else t
+                   for o, t in zip(own, tensors)]
+        todo = [(v, t) for o, v, t in zip(own, pk.views, tensors) if not o]
         if todo:  # statistics that were not produced in place: one multi-tensor copy into the slots
             torch._foreach_copy_([v for v, _ in todo], [t.expand(v.shape) for v, t in todo])
         dist.all_reduce(pk.flat, op=dist.ReduceOp.SUM, group=self.group)
         self.calls += 1
-        return [v if t.dtype == dt else v.to(t.dtype) for v, t in zip(pk.views, tensors)]
+        if all(own):
+            return list(pk.views)
+        fresh, out, off = pk.flat.clone(), [], 0
+        for o, v, t in zip(own, pk.views, tensors):
+            r = v if o else fresh[off:off + v.numel()].view(v.shape)
+            off += v.numel()
+            out.append(r if t.dtype == dt else r.to(t.dtype))
+        return out

@@ -92,3 +92,42 @@ def test_reducer_single_process_is_identity():
     a, b = torch.randn(3, 2), torch.randn(())
     x, y = r.all_reduce([a, b])
     assert torch.equal(x, a) and torch.equal(y, b) and r.calls == 0
+
+
+def _alias_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pyvbmp_amd.parallel import SuffStatReducer
+        red = SuffStatReducer()
+        a = [torch.full((3,), 1.0 + rank, dtype=torch.float64), torch.full((2, 2), 10.0 + rank, dtype=torch.float64)]
+        b = [torch.full((3,), 100.0 + rank, dtype=torch.float64), torch.full((2, 2), 1000.0 + rank, dtype=torch.float64)]
+        ra = red.all_reduce(a)          # "model A"
+        keep = [t.clone() for t in ra]
+        rb = red.all_reduce(b)          # "model B": same signature, same reducer
+        ok = all(torch.equal(x, y) for x, y in zip(ra, keep))   # A's results survive B's exchange
+        ok = ok and torch.equal(rb[0], torch.full((3,), 201.0, dtype=torch.float64))
+        # slot views come back in place; a slot view passed back at ANOTHER position must not be clobbered
+        sl = red.slots([(3,), (3,)], torch.float64, torch.device("cpu"))
+        sl[0].fill_(1.0 + rank)
+        sl[1].fill_(5.0 + rank)
+        r1 = red.all_reduce(sl)
+        ok = ok and r1[0].data_ptr() == sl[0].data_ptr() and torch.equal(r1[1], torch.full((3,), 11.0, dtype=torch.float64))
+        sl[0].fill_(1.0)
+        sl[1].fill_(2.0)
+        r2 = red.all_reduce([sl[1], sl[0]])  # swapped
+        ok = ok and torch.equal(r2[0], torch.full((3,), 4.0, dtype=torch.float64)) and torch.equal(r2[1], torch.full((3,), 2.0, dtype=torch.float64))
+        if rank == 0:
+            torch.save({"ok": bool(ok), "calls": red.calls}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reducer_results_do_not_alias_across_exchanges(tmp_path):
+    """two same-shaped models on one reducer / a result kept across iterations / a slot view passed back at another
+    position -- none may be overwritten by a later exchange of the same signature"""
+    out = str(tmp_path / "alias.pt")
+    mp.spawn(_alias_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = torch.load(out)
+    assert res["ok"] and res["calls"] == 4

@@ -1,4 +1,4 @@
-"""K9 block form at the flocking DMBD's hidden dimension (52): compile-time H instance vs the generic one (flag 0x4000), interleaved"""
+"""K9 block form at the flocking DMBD's hidden dimension (52): compile-time H instance vs the generic one (flag 0x2000000), interleaved"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -6,7 +6,7 @@ from pyvbmp_amd import _lib
 from pyvbmp_amd.models import LinearDynamicalSystems
 lib = _lib.load()
 lib.vbmp_debug_set_flags.argtypes = [ctypes.c_int]
-flags = [int(v, 0) for v in (sys.argv[1:] or ["0", "0x4000"])]
+flags = [int(v, 0) for v in (sys.argv[1:] or ["0", "0x2000000"])]
 for dt in (torch.float64, torch.float32):
     h, T, S = 52, 100, 20
     g = torch.Generator(device="cuda").manual_seed(0)

@@ -10,7 +10,7 @@ for dt in (torch.float64, torch.float32):
     y = torch.randn(T, S, 6, generator=g, device="cuda", dtype=dt).cumsum(0) * 0.05
     m = LinearDynamicalSystems((6,), h, latent_noise='shared', device="cuda", dtype=dt)
     yy, uu, rr = m.reshape_inputs(y); m.update_latents(yy, uu, rr)
-    for f in (0, 0x4000, 0, 0x4000):
+    for f in (0, 0x2000000, 0, 0x2000000):
         lib.vbmp_debug_set_flags(f)
         ev = []
         def rec(n):
