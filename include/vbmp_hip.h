@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VBMP_ABI_VERSION 5
+#define VBMP_ABI_VERSION 6
 int vbmp_abi_version(void);
 
 /* K1 -- Ainv = A^-1 and logdet = log det A of B symmetric positive definite matrices.
@@ -295,6 +295,18 @@ int vbmp_rows_affine_f64(const double* X, int64_t S, int k, const double* M, con
                          void* stream);
 int vbmp_rows_affine_f32(const float* X, int64_t S, int k, const float* M, const float* c, int n, float* out,
                          void* stream);
+/* K13 -- the parameter expectations a mixture E-step reads from a Normal-inverse-Wishart posterior, in one launch (replaces the
+ * getters NormalInverseWishart.EinvSigma / EinvSigmamu / EXTinvUX / ElogdetinvSigma, dists/NormalInverseWishart.py:107-132 as used
+ * by Elog_like :91-97, Wishart.ElogdetinvSigma dists/Wishart.py:82-83 and Dirichlet.loggeomean dists/Dirichlet.py:52-53):
+ *     P[k] = U[k] nu[k],  b[k] = P[k] mu[k],
+ *     c[k] = -1/2 (mu' P mu + D / lambda) + 1/2 (D log 2 - logdet_invU + sum_{i<D} psi((nu - i) / 2)) - D/2 log 2 pi
+ *            + (alpha ? psi(alpha[k]) - psi(sum_j alpha[j]) : 0)
+ * so that  -1/2 x' P x + x' b + c  is E log N(x | component k) (+ E log pi_k): the operands of vbmp_mixture_estep.  All dense:
+ * U (K,D,D), nu / lam / logdet_invU / alpha (K), mu (K,D); outputs P (K,D,D), b (K,D), c (K).  alpha nullable.  D >= 1. */
+int vbmp_niw_estep_params_f64(const double* U, const double* nu, const double* mu, const double* lam, const double* logdet_invU,
+                              const double* alpha, int64_t K, int D, double* P, double* b, double* c, void* stream);
+int vbmp_niw_estep_params_f32(const float* U, const float* nu, const float* mu, const float* lam, const float* logdet_invU,
+                              const float* alpha, int64_t K, int D, float* P, float* b, float* c, void* stream);
 /* K12 with the observation likelihood's scalar in the same pass: additionally q[s] = -1/2 x' P x + b' x + c0[0]
  * (LinearDynamicalSystems.log_likelihood_function, models/LinearDynamicalSystems.py:244-266: invSigmamu_t and Residual of
  * every (time, series) from ONE read of the observations).  P dense (k,k); b (k) or NULL; c0 one element in device memory or

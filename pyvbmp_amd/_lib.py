@@ -16,7 +16,7 @@ _c_i64 = ctypes.c_int64
 _c_int = ctypes.c_int
 _c_ptr = ctypes.c_void_p
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 
@@ -143,6 +143,8 @@ SYMBOLS = {
     "vbmp_weighted_matsum": _sig_matsum,
     "vbmp_weighted_matsum_cols": _sig_matsum_cols,
     "vbmp_rows_affine": _sig_rows,
+    # U, nu, mu, lam, logdet_invU, alpha, K, D, P, b, c, stream
+    "vbmp_niw_estep_params": lambda T: [_c_ptr] * 6 + [_c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
     # X, S, k, M, c, n, out, P, b, c0, q, stream
     "vbmp_rows_affine_quad": lambda T: [_c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
 }

@@ -48,9 +48,15 @@ class Mixture():
 
     def update_assignments(self, X):
         if self._fusable(X):
-            P, b, c = self.dist.mixture_estep_params()
+            # the component expectations AND E log pi in one launch (K13) when the mixing weights are a plain Dirichlet
+            alpha = getattr(self.pi, "alpha", None)
+            if alpha is not None and alpha.ndim == 1:
+                P, b, c = self.dist.mixture_estep_params(alpha=alpha)
+            else:
+                P, b, c = self.dist.mixture_estep_params()
+                c = c + self.pi.loggeomean()
             sample_shape = tuple(X.shape[:-1])
-            p, NA, logZ = ops.mixture_estep(X.reshape(-1, X.shape[-1]), P, b, c + self.pi.loggeomean())
+            p, NA, logZ = ops.mixture_estep(X.reshape(-1, X.shape[-1]), P, b, c)
             self.p = p.reshape(sample_shape + self.event_shape)
             self.NA = NA
             self.logZ = logZ

@@ -126,11 +126,17 @@ class NormalInverseWishart():
             out = out.sum(-1)
         return out
 
-    def mixture_estep_params(self):
+    def mixture_estep_params(self, alpha=None):
         """(P, b, c) of the quadratic form  -1/2 x^T P x + x^T b + c  = Elog_like(x), per component
-        (fed to the fused mixture E-step kernel K3)."""
+        (fed to the fused mixture E-step kernel K3); with the Dirichlet counts `alpha` of the mixing weights c also carries
+        E log pi_k.  One launch (K13) for a plain vector-valued family on the device; the getters otherwise."""
         W = self.invU
+        if self.mu.is_cuda and self.event_dim == 1 and self.batch_dim == 1 and self.dim <= 64:
+            from .. import ops
+            return ops.niw_estep_params(W.U, W.nu, self.mu, self.lambda_mu, W.logdet_invU, alpha)
         c = -0.5 * self.EXTinvUX() + 0.5 * W.ElogdetinvSigma() - 0.5 * self.dim * _LOG2PI
+        if alpha is not None:
+            c = c + torch.digamma(alpha) - torch.digamma(alpha.sum(-1, True))
         return W.EinvSigma(), self.EinvSigmamu(), c
 
     def KLqprior(self):

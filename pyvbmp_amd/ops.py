@@ -609,6 +609,25 @@ def rows_affine_quad(X, M, c, P, b, c0):
     return out, q
 
 
+def niw_estep_params(U, nu, mu, lam, logdet_invU, alpha=None):
+    """K13: (P, b, c) with -1/2 x' P x + x' b + c = E log N(x | component k) (+ E log pi_k when the Dirichlet counts `alpha` are
+    given) for K Normal-inverse-Wishart components, one launch.  U (K,D,D), nu / lam / logdet_invU / alpha (K), mu (K,D)."""
+    dev = L.require_device(U, nu, mu, lam, logdet_invU, alpha)
+    lib = L.load()
+    dt = U.dtype
+    K, D = mu.shape
+    assert U.shape == (K, D, D)
+    ops_in = [t.to(dt).reshape(sh).contiguous() for t, sh in ((U, (K, D, D)), (nu, (K,)), (mu, (K, D)), (lam, (K,)), (logdet_invU, (K,)))]
+    al = None if alpha is None else alpha.to(dt).reshape(K).contiguous()
+    P = torch.empty(K, D, D, dtype=dt, device=dev)
+    b = torch.empty(K, D, dtype=dt, device=dev)
+    c = torch.empty(K, dtype=dt, device=dev)
+    if K > 0:
+        fn = getattr(lib, "vbmp_niw_estep_params_" + L.suffix(dt))
+        L.call(fn, "vbmp_niw_estep_params", *[L.ptr(t) for t in ops_in], L.ptr(al), K, D, L.ptr(P), L.ptr(b), L.ptr(c), L.stream_ptr(dev))
+    return P, b, c
+
+
 MATSUM_MAX_COLS = 32
 
 

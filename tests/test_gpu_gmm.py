@@ -339,3 +339,39 @@ def test_graph_lifetime_is_deterministic_and_survives_a_delete_during_capture():
         assert not b.__dict__["_vbmp_graphs"]
     finally:
         gc.enable()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 2e-5)])
+@pytest.mark.parametrize("K,D", [(1, 2), (4, 16), (7, 5), (70, 40), (3, 64)])
+def test_niw_estep_params_kernel_against_the_getters(K, D, dtype, tol):
+    """K13 (one launch: P = U nu, b = P mu, c with the digamma sums and E log pi) against the composition of the classes' getters
+    (ref dists/NormalInverseWishart.py:91-97,107-132, dists/Wishart.py:82-83, dists/Dirichlet.py:52-53) after a real update"""
+    from pyvbmp_amd import ops
+    from pyvbmp_amd.dists import NormalInverseWishart
+    g = torch.Generator().manual_seed(K * 100 + D)
+    q = NormalInverseWishart((D,), (K,), device=DEV, dtype=dtype)
+    A = torch.randn(K, D, D + 3, generator=g, dtype=torch.float64)
+    SExx, SEx = (A @ A.transpose(-2, -1)).to(dtype).to(DEV), A.sum(-1).to(dtype).to(DEV)
+    N = (D + 3.0 + torch.arange(K, dtype=torch.float64)).to(dtype).to(DEV)
+    q.ss_update(SExx, SEx, N, lr=1.0, beta=None)
+    alpha = (0.3 + torch.rand(K, generator=g, dtype=torch.float64) * 5).to(dtype).to(DEV)
+    W = q.invU
+    P0, b0 = W.EinvSigma(), q.EinvSigmamu()
+    c0 = -0.5 * q.EXTinvUX() + 0.5 * W.ElogdetinvSigma() - 0.5 * D * 1.8378770664093453
+    for al in (None, alpha):
+        P, b, c = ops.niw_estep_params(W.U, W.nu, q.mu, q.lambda_mu, W.logdet_invU, al)
+        cref = c0 if al is None else c0 + torch.digamma(al) - torch.digamma(al.sum())
+        assert_close(P, P0, tol, what="P")
+        assert_close(b, b0, tol, what="b")
+        assert_close(c, cref, tol, what="c")
+    # small arguments of the digamma recurrence (nu close to D - 1, tiny alpha)
+    W2nu = torch.full((K,), D - 1 + 1e-3, dtype=dtype, device=DEV)
+    al2 = torch.full((K,), 1e-3, dtype=dtype, device=DEV)
+    _, _, c = ops.niw_estep_params(W.U, W2nu, q.mu, q.lambda_mu, W.logdet_invU, al2)
+    ar = torch.arange(D, dtype=dtype, device=DEV)
+    P2 = W.U * W2nu.reshape(K, 1, 1)
+    quad = ((P2 @ q.mu.unsqueeze(-1)).squeeze(-1) * q.mu).sum(-1)
+    cref = -0.5 * (quad + D / q.lambda_mu.reshape(K)) + 0.5 * (D * 0.6931471805599453 - W.logdet_invU.reshape(K)
+           + torch.digamma(0.5 * W2nu.unsqueeze(-1) - 0.5 * ar).sum(-1)) - 0.5 * D * 1.8378770664093453 \
+           + torch.digamma(al2) - torch.digamma(al2.sum())
+    assert_close(c, cref, tol * 10, what="c at small arguments")
