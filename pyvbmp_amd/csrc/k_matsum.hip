@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "vbmp_dispatch.h"
+#include "vbmp_flags.h"
+extern "C" int g_vbmp_flags;
 #include "../../include/vbmp_hip.h"
 
 namespace vbmp {
@@ -119,6 +121,132 @@ __global__ __launch_bounds__(256) void k_weighted_matsum_cols(const T* __restric
   }
 }
 
+// The same sum on the matrix cores, for MANY weight columns (round 3).  With 25 role columns on 52 x 52 matrices (the flocking
+// DMBD) the form above spends 64 FMAs and 32 LDS broadcast reads per 16 bytes it loads and runs at 1.0 TB/s; as a product
+// out (NB x E) = W' (NB x S) C (S x E) over the samples it is 16x16x4 MFMA steps: A[i][k] = W[s0 + k][b0 + i], B[k][j] = C[s0 + k][e(j)].
+// A lane loads 16 bytes of a sample's row -- V consecutive elements -- and feeds V column tiles with them: tile u's column j IS
+// element e0 + V j + u (any bijection serves, the epilogue stores with the same map), so the row is read with full 16-byte lanes.
+// Wave w of a block owns 64 elements (NL = 64 / (16 V) loads per 4 samples); NBT = 1 or 2 row tiles of 16 weight columns.
+typedef double ms_f64x4 __attribute__((ext_vector_type(4)));
+typedef float ms_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ ms_f64x4 ms_mfma(double a, double b, ms_f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ ms_f32x4 ms_mfma(float a, float b, ms_f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+template <typename T> struct MsAcc;
+template <> struct MsAcc<double> { using type = ms_f64x4; static __device__ __forceinline__ int row(int r, int g) { return g + 4 * r; } };
+template <> struct MsAcc<float> { using type = ms_f32x4; static __device__ __forceinline__ int row(int r, int g) { return 4 * g + r; } };
+
+template <typename T, int NBT>
+__global__ __launch_bounds__(256) void k_weighted_matsum_cols_mfma(const T* __restrict__ C, const T* __restrict__ W, int64_t S,
+                                                                   int64_t E, int NB, int64_t chunk, T* __restrict__ out) {
+  constexpr int V = 16 / sizeof(T);   // elements per lane and load = column tiles per load
+  constexpr int NL = 64 / (16 * V);   // loads per wave and k step (64 elements per wave)
+  using vec_t = T __attribute__((ext_vector_type(V)));
+  using acc_t = typename MsAcc<T>::type;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, f = lane & 15;
+  const int64_t s0 = (int64_t)blockIdx.y * chunk;
+  const int64_t s1 = (s0 + chunk < S) ? s0 + chunk : S;
+  const int64_t e_wave = ((int64_t)blockIdx.x * 4 + wave) * 64;  // first element of this wave
+  if (e_wave >= E) return;                                      // (no block barrier below)
+  // my 16-byte piece of load n: elements e_wave + 16 V n + V f .. + V - 1 (clamped into the row: stores are guarded)
+  int64_t eo[NL];
+#pragma unroll
+  for (int n = 0; n < NL; ++n) {
+    const int64_t e = e_wave + 16 * V * n + V * f;
+    eo[n] = e + V <= E ? e : E - V;
+  }
+  acc_t acc[NBT][NL * V];
+#pragma unroll
+  for (int bt = 0; bt < NBT; ++bt)
+#pragma unroll
+    for (int t = 0; t < NL * V; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[bt][t][r] = T(0);
+  int bcol[NBT];
+  bool bok[NBT];
+#pragma unroll
+  for (int bt = 0; bt < NBT; ++bt) {
+    bok[bt] = 16 * bt + f < NB;
+    bcol[bt] = bok[bt] ? 16 * bt + f : 0;
+  }
+  auto load = [&](int64_t sb, vec_t (&bv)[NL], T (&av)[NBT]) {
+    const int64_t s = sb + q;
+    const bool sok = s < s1;
+    const int64_t sc = sok ? s : s1 - 1;
+#pragma unroll
+    for (int n = 0; n < NL; ++n) bv[n] = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(C + sc * E + eo[n]));
+#pragma unroll
+    for (int bt = 0; bt < NBT; ++bt) {
+      const T w = W[sc * NB + bcol[bt]];
+      av[bt] = (sok && bok[bt]) ? w : T(0);  // a sample past the slab or a column past NB contributes nothing
+    }
+  };
+  constexpr int U = 2;  // k steps in flight
+  vec_t bv[U][NL];
+  T av[U][NBT];
+  int64_t sb = s0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) load(sb + 4 * u, bv[u], av[u]);
+  for (; sb < s1; sb += 4 * U) {
+    vec_t bc[U][NL];
+    T ac[U][NBT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int n = 0; n < NL; ++n) bc[u][n] = bv[u][n];
+#pragma unroll
+      for (int bt = 0; bt < NBT; ++bt) ac[u][bt] = av[u][bt];
+    }
+    if (sb + 4 * U < s1) {  // wave-uniform: the next U steps' operands while these multiply
+#pragma unroll
+      for (int u = 0; u < U; ++u) load(sb + 4 * U + 4 * u, bv[u], av[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int bt = 0; bt < NBT; ++bt)
+#pragma unroll
+        for (int n = 0; n < NL; ++n)
+#pragma unroll
+          for (int v = 0; v < V; ++v) acc[bt][n * V + v] = ms_mfma(ac[u][bt], bc[u][n][v], acc[bt][n * V + v]);
+  }
+  // C tile (bt, n, v): column j = f is element e_wave + 16 V n + V f + v, rows i = MsAcc::row(r, q) are weight columns 16 bt + i
+#pragma unroll
+  for (int bt = 0; bt < NBT; ++bt)
+#pragma unroll
+    for (int n = 0; n < NL; ++n)
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const int64_t e = e_wave + 16 * V * n + V * f + v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int b = 16 * bt + MsAcc<T>::row(r, q);
+          if (b < NB && e < E) atomicAdd(&out[(int64_t)b * E + e], acc[bt][n * V + v][r]);
+        }
+      }
+}
+
+template <typename T>
+static int matsum_cols_mfma_launch(const T* C, const T* W, int64_t S, int64_t E, int NB, T* out, hipStream_t st) {
+  const int64_t bx = (E + 255) / 256;
+  // sample slabs: enough blocks to fill the chip, few enough that the final atomics (NB x 256 per block) stay short
+  int64_t by = (768 + bx - 1) / bx;
+  int64_t chunk = (S + by - 1) / by;
+  chunk = (chunk + 7) / 8 * 8;
+  if (chunk < 64) chunk = 64;
+  by = (S + chunk - 1) / chunk;
+  if (by > 65535) {
+    by = 65535;
+    chunk = ((S + by - 1) / by + 7) / 8 * 8;
+    by = (S + chunk - 1) / chunk;
+  }
+  const dim3 grid((unsigned)bx, (unsigned)by);
+  if (NB <= 16)
+    hipLaunchKernelGGL((k_weighted_matsum_cols_mfma<T, 1>), grid, dim3(256), 0, st, C, W, S, E, NB, chunk, out);
+  else
+    hipLaunchKernelGGL((k_weighted_matsum_cols_mfma<T, 2>), grid, dim3(256), 0, st, C, W, S, E, NB, chunk, out);
+  return hipGetLastError() == hipSuccess ? 0 : VBMP_ERR_LAUNCH;
+}
+
 template <typename T, int V>
 static int matsum_cols_launch(const T* C, const T* W, int64_t S, int64_t E, int NB, T* out, hipStream_t st) {
   int64_t bx = (E / V + 255) / 256;
@@ -149,7 +277,11 @@ static int matsum_cols_dispatch(const T* C, const T* W, int64_t S, int64_t E, in
   if (!C || !W || !out || S < 0 || E < 0 || NB < 1 || NB > VBMP_MATSUM_MAX_COLS) return VBMP_ERR_ARG;
   constexpr int V = 16 / sizeof(T);
   hipStream_t st = (hipStream_t)stream;
-  if (E % V == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0) return matsum_cols_launch<T, V>(C, W, S, E, NB, out, st);
+  const bool vec_ok = E % V == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+  // many columns: the matrix-core form (the VALU form is HBM-bound up to 8 columns and FMA / LDS-bound beyond);
+  // VBMP_DBG_MATSUM_VALU: the VALU form (tests, A/B timing)
+  if (vec_ok && NB > 8 && E >= V && S >= 64 && !(g_vbmp_flags & VBMP_DBG_MATSUM_VALU)) return matsum_cols_mfma_launch<T>(C, W, S, E, NB, out, st);
+  if (vec_ok) return matsum_cols_launch<T, V>(C, W, S, E, NB, out, st);
   return matsum_cols_launch<T, 1>(C, W, S, E, NB, out, st);  // odd d: d*d elements per matrix, one element per lane
 }
 

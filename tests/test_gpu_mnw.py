@@ -225,7 +225,11 @@ def test_rows_matmul_routes_many_rows_through_k12():
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 @pytest.mark.parametrize("S,inner,NB", [(24000, (53, 53), 25), (25600, (7, 7), 4), (5000, (8, 8), 1), (70, (4, 4), 32), (333, (3,), 5),
-                                        (100, (6, 6), 33)])
+                                        (100, (6, 6), 33),
+                                        # the matrix-core form (> 8 columns, even element count): the flocking DMBD's 52 x 52 by 25 roles,
+                                        # ragged sample / element / column counts, one and two row tiles, a single k step
+                                        (24000, (52, 52), 25), (1003, (10, 10), 9), (64, (4, 4), 16), (67, (6, 6), 17), (4099, (32, 32), 32),
+                                        (130, (2,), 12), (3001, (9, 14), 31)])
 def test_weighted_matsum_cols(S, inner, NB, dtype):
     """K5b with a weight column per expert against W^T @ C (odd and even matrix sizes, up to and beyond the column limit)"""
     from pyvbmp_amd import ops
