@@ -131,9 +131,16 @@ class NormalInverseWishart():
         (fed to the fused mixture E-step kernel K3); with the Dirichlet counts `alpha` of the mixing weights c also carries
         E log pi_k.  One launch (K13) for a plain vector-valued family on the device; the getters otherwise."""
         W = self.invU
-        if self.mu.is_cuda and self.event_dim == 1 and self.batch_dim == 1 and self.dim <= 64:
+        lead = tuple(self.mu.shape[:-1])  # batch + leading event axes: one "component" each
+        if self.mu.is_cuda and self.dim <= 64 and (alpha is None or (len(lead) == 1 and alpha.shape == lead)):
             from .. import ops
-            return ops.niw_estep_params(W.U, W.nu, self.mu, self.lambda_mu, W.logdet_invU, alpha)
+            K, D = 1, self.dim
+            for n in lead:
+                K *= n
+            P, b, c = ops.niw_estep_params(W.U.expand(lead + (D, D)).reshape(K, D, D), W.nu.expand(lead).reshape(K),
+                                           self.mu.reshape(K, D), self.lambda_mu.expand(lead).reshape(K),
+                                           W.logdet_invU.expand(lead).reshape(K), alpha)
+            return P.reshape(lead + (D, D)), b.reshape(lead + (D,)), c.reshape(lead)
         c = -0.5 * self.EXTinvUX() + 0.5 * W.ElogdetinvSigma() - 0.5 * self.dim * _LOG2PI
         if alpha is not None:
             c = c + torch.digamma(alpha) - torch.digamma(alpha.sum(-1, True))

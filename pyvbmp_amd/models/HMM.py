@@ -12,10 +12,6 @@ from .. import ops
 from ..dists.Dirichlet import Dirichlet
 
 
-def _lse(x, dim, keepdim=False):
-    return torch.logsumexp(x, dim, keepdim=keepdim)
-
-
 class HMM():
     def __init__(self, obs_dist, transition_mask=None, ptemp=1.0):
         self.obs_dist = obs_dist
@@ -43,32 +39,13 @@ class HMM():
         (time first).  ref models/HMM.py:72-105.  Returns p, SEzz, SEz0, logZ."""
         trans = self.transition.loggeomean()
         init = self.initial.loggeomean()
-        if self.dim <= ops.L.HMM_MAX_K:
-            # ONE persistent launch (K11) instead of two host loops over time
-            return ops.hmm_forward_backward(fw_logits, trans, init, self.batch_shape, self.ptemp)
-        T = fw_logits.shape[0]
-        fw = [None] * T
-        fw[0] = _lse(init.unsqueeze(-1) + trans + fw_logits[0].unsqueeze(-2), -2)
-        for t in range(1, T):
-            fw[t] = _lse(fw[t - 1].unsqueeze(-1) + trans + fw_logits[t].unsqueeze(-2), -2)
-        logZ = _lse(fw[-1], -1, True)
-        fw = [f - logZ for f in fw]
-        logZ = logZ.squeeze(-1)
-        SEzz = torch.zeros(tuple(fw[0].shape) + self.event_shape, device=fw[0].device, dtype=fw[0].dtype)
-        for t in range(T - 2, -1, -1):
-            temp = fw[t].unsqueeze(-1) + trans
-            xi = (temp - _lse(temp, -2, True)) + fw[t + 1].unsqueeze(-2)
-            fw[t] = _lse(xi, -1)
-            SEzz = SEzz + (xi - _lse(xi, (-1, -2), True)).exp()
-        temp = init.unsqueeze(-1) + trans
-        xi = (temp - _lse(temp, -2, True)) + fw[0].unsqueeze(-2)
-        SEz0 = _lse(xi, -1)
-        SEz0 = (SEz0 - _lse(SEz0, -1, True)).exp()
-        SEzz = SEzz + (xi - _lse(xi, (-1, -2), True)).exp()
-        p = torch.stack(fw)
-        p = ((p - p.max(-1, keepdim=True)[0]) / self.ptemp).exp()
-        p = p / p.sum(-1, keepdim=True)
-        return p, SEzz, SEz0, logZ
+        if self.dim > ops.L.HMM_MAX_K:
+            # every model of the reference stays far below (25 roles in the flocking DMBD); a host loop over time in torch ops
+            # would be the silent slow path this package does not have
+            raise ops.L.VbmpHipError(f"HMM with {self.dim} states: the forward-backward kernel (K11) holds a chain's transition "
+                                     f"column in registers and serves up to VBMP_HMM_MAX_K = {ops.L.HMM_MAX_K} states")
+        # ONE persistent launch (K11) instead of two host loops over time
+        return ops.hmm_forward_backward(fw_logits, trans, init, self.batch_shape, self.ptemp)
 
     def assignment_pr(self):
         return self.p

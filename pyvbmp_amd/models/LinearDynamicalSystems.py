@@ -386,10 +386,12 @@ class LinearDynamicalSystems():
         cu2 = (self.ATQA_x_u @ Uc).squeeze(-1)
         cu3 = (_T(Uc) @ self.ATQA_u_u @ Uc).squeeze(-1).squeeze(-1)
         x0 = self.x0
-        x0_res = -0.5 * x0.EXTinvUX() + 0.5 * x0.ElogdetinvSigma() - 0.5 * h * _LOG2PI
+        # E[invSigma], E[invSigma mu] and -1/2 EXTinvUX + 1/2 ElogdetinvSigma - h/2 log 2 pi of the initial-state prior: exactly the
+        # (P, b, c) of its expected log density, one launch (K13) instead of the four getters' sixteen
+        x0_P, x0_eta, x0_res = x0.mixture_estep_params()
         if h <= ops.L.LDS_MAX_H or (h <= ops.L.LDS_MAX_H_BLOCK and ops.L.lds_block_fits(h, y.element_size())):
             out = ops.lds_smoother(T_max, sample_shape, bo_shape, h, self.invQ, self.ATQA_x_x, self.QA_xp_x,
-                                   self.A.ElogdetinvSigma(), x0.EinvSigma(), x0.EinvSigmamu(), x0_res,
+                                   self.A.ElogdetinvSigma(), x0_P, x0_eta, x0_res,
                                    invSigma_like, invSigmamu_like.squeeze(-1), Residual_like, cu1, cu2, cu3,
                                    sums_only=sums_only, y=y.squeeze(-1) if (sums_only and len(self.offset) == 0) else None,
                                    fixed_point=self.fixed_point if fixed_point is None else fixed_point)

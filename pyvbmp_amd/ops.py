@@ -65,6 +65,11 @@ def spd_inv_logdet(A, want_logdet=True, nonspd=None):
     if D > L.MAX_DIM:
         # beyond the one-wave-per-matrix kernels (VBMP_MAX_DIM = 64): the device library's factorisations (rocSOLVER through
         # torch.linalg, still on the GPU); Tensor.logdet keeps the reference's NaN / -inf semantics
+        nonspd, own = _spd_counter(dev, nonspd)
+        if nonspd is not None and B > 0:
+            # the library route has no pivot counter: count the matrices whose Cholesky factorisation fails (no host sync)
+            nonspd += (torch.linalg.cholesky_ex(A).info.reshape(-1) != 0).sum().to(torch.int32)
+            _spd_verify(nonspd, own, "spd_inv_logdet")
         return torch.linalg.inv(A), (torch.logdet(A) if want_logdet else None)
     Ac = A.contiguous()
     Ainv = torch.empty_like(Ac)
@@ -210,6 +215,13 @@ def quadform_loglike(X, P, b, c):
     return out.reshape(sample_shape + mat_batch)
 
 
+def estep_sym_serves(S, K, D, dt):
+    """does the symmetric-packed form of K3 (`vbmp_mixture_estep_sym`, the only form that also returns the per-sample evidence)
+    serve S samples of K components in D dimensions?  Callers test this BEFORE assembling operands they would throw away."""
+    return S > 0 and (D in (4, 8, 16) or (D == 32 and dt == torch.float32)) and K <= ESTEP_SYM_MAX_K and S >= 4096 \
+        and not _estep_sym_off
+
+
 def mixture_estep(X, P, b, c, want_lse=False):
     """K3: fused responsibilities for a K-component mixture over dense samples X (S,D).
     c must already include E log pi.  Returns p (S,K), NA (K), logZ ().
@@ -221,8 +233,7 @@ def mixture_estep(X, P, b, c, want_lse=False):
     dt = P.dtype
     Xc = X.to(dt).contiguous()
     S = Xc.shape[0]
-    sym = S > 0 and (D in (4, 8, 16) or (D == 32 and dt == torch.float32)) and K <= ESTEP_SYM_MAX_K and S >= 4096 \
-        and not _estep_sym_off
+    sym = estep_sym_serves(S, K, D, dt)
     if want_lse and not sym:
         return None
     p = torch.empty((S, K), dtype=dt, device=dev)

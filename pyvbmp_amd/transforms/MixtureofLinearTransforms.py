@@ -48,8 +48,12 @@ class MixtureofLinearTransforms():
 
     def update_assignments(self, X, Y):
         W = self.W
+        n_samples = 1
+        for v in X.shape[:-2]:
+            n_samples *= v
         if self.batch_dim == 0 and hasattr(W, '_joint_quadratic') and W.event_dim == 2 and X.is_cuda and X.ndim >= 3 and Y.ndim == X.ndim \
-                and tuple(X.shape[:-2]) == tuple(Y.shape[:-2]):
+                and tuple(X.shape[:-2]) == tuple(Y.shape[:-2]) \
+                and ops.estep_sym_serves(n_samples, self.dim, X.shape[-2] + Y.shape[-2], X.dtype):  # (asked before Z, P, b, c are built)
             # unbatched mixture over dense samples: likelihood, softmax and evidence in ONE fused launch (K3, symmetric-packed
             # form) on the stacked vector z = [x; y]; None when the shape is outside that kernel form
             P, b, c = W._joint_quadratic()

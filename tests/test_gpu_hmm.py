@@ -123,3 +123,28 @@ def test_hmm_revived_state_needs_the_log_space_step(dtype):
     assert_close(SEzz, rzz, tol, what="SEzz")
     assert_close(SEz0, rz0, tol, what="SEz0")
     assert_close(logZ, rlz, tol, what="logZ")
+
+
+def test_hmm_beyond_the_kernel_limit_raises():
+    """more than VBMP_HMM_MAX_K = 64 states: a VbmpHipError naming the limit (no host-loop fallback)"""
+    from pyvbmp_amd import _lib
+    from pyvbmp_amd.dists import NormalInverseWishart
+    from pyvbmp_amd.models import HMM
+    K = 65
+    m = HMM(NormalInverseWishart((2,), (K,), device=DEV, dtype=torch.float64))
+    with pytest.raises(_lib.VbmpHipError, match="VBMP_HMM_MAX_K"):
+        m.forward_backward_logits(torch.zeros(3, K, device=DEV, dtype=torch.float64))
+    # extreme logits and a sharp chain: the extended-range step is the only step there is now
+    from pyvbmp_amd import ops
+    lg = torch.zeros(40, 3, 25, dtype=torch.float64, device=DEV)
+    lg[..., 7] = 5000.0
+    lg[20:, :, 7] = -5000.0
+    lg[20:, :, 3] = 4000.0
+    tr = torch.log_softmax(torch.randn(25, 25, dtype=torch.float64, generator=torch.Generator().manual_seed(1)), -1).to(DEV)
+    ini = torch.log_softmax(torch.zeros(25, dtype=torch.float64), -1).to(DEV)
+    p, SEzz, SEz0, logZ = ops.hmm_forward_backward(lg, tr, ini, ())
+    from oracle import hmm as ohmm
+    po, So, S0o, lzo = ohmm.forward_backward(lg.cpu(), tr.cpu(), ini.cpu())
+    assert_close(p, po, 1e-10, what="p")
+    assert_close(SEzz, So, 1e-10, what="SEzz")
+    assert_close(logZ, lzo, 1e-10, what="logZ")

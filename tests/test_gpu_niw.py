@@ -321,3 +321,13 @@ def test_debug_check_spd_raises_on_an_indefinite_matrix():
         with pytest.raises(_lib.VbmpHipError, match="1 matrices"):
             ops.spd_inv_logdet(A)
     assert ops.CHECK_SPD is False
+    # beyond the kernels' matrix size (D > 64: the device library's factorisation) the counter / the debug check cover the call too
+    B = torch.eye(70, dtype=torch.float64, device=DEV).repeat(4, 1, 1)
+    B[1, 5, 5] = -2.0
+    cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.spd_inv_logdet(B, nonspd=cnt)
+    assert int(cnt) == 1
+    with debug.check_spd():
+        ops.spd_inv_logdet(B[2:])
+        with pytest.raises(_lib.VbmpHipError, match="1 matrices"):
+            ops.spd_inv_logdet(B)
