@@ -21,4 +21,4 @@
 #define VBMP_DBG_BLK_GENERIC    0x2000000  /* K9 block form: run-time-H instance instead of the compile-time ones */
 #define VBMP_DBG_BLK_MONO       0x4000000  /* K9 block form: one block per series for the whole sweep (no forward / Gamma-chain split) */
 #define VBMP_DBG_MATSUM_VALU    0x8000000  /* K5b: VALU form for any number of weight columns (no matrix-core form) */
-#define VBMP_DBG_SCHED_SHIFT    28         /* K1/K2: bits 28-29 = 4 / 16 / 2 tile groups instead of 8 */
+#define VBMP_DBG_SCHED_SHIFT    28         /* K1/K2: bits 28-29 = 8 / 16 / 2 tile groups instead of 4 */
