@@ -582,7 +582,8 @@ def test_lds_fixed_point_shortcut_contraction_sweep_against_the_oracle(one_minus
     observations) from fast to near-unit-root.  The default mode may take the rounding criterion only while the recursion is
     seen to contract (csrc/k_lds_g16.inc), so: (i) against the fp64 ORACLE every output meets the north-star tolerance or is as
     close as the literal recursion in the same precision is (an ill-conditioned system in fp32 is ill-conditioned for both);
-    (ii) where the recursion creeps ("slow"), default == exact mode == literal recursion BIT FOR BIT."""
+    (ii) exact mode == literal recursion BIT FOR BIT, default mode within the contract's last-bit wander of it (1e-13 / 2e-6), however
+    slowly the recursion contracts."""
     from oracle import lds as olds
     from oracle import mnw as omnw
     from oracle import niw as oniw
@@ -632,6 +633,9 @@ def test_lds_fixed_point_shortcut_contraction_sweep_against_the_oracle(one_minus
           {k: f"{v:.1e}" for k, v in diffs.items()})
     for k, v in diffs.items():
         assert v <= max(64 * eps, 16 * move), f"{k}: default mode {v:.2e} from the literal recursion, which moves {move:.1e} per step"
-    if one_minus_rate <= 3e-4 and move > 64 * eps:  # the near-unit-root systems creep for the whole series: nothing may stop them
-        for k in outs["off"]:
-            assert torch.equal(outs["auto"][k], outs["off"][k]), f"{k}: stopped while the covariance still moved by {move:.1e} per step"
+    # ... and never further than the accuracy contract of the default mode (include/vbmp_hip.h): the literal recursion's own last-bit
+    # wander -- also where the smoothed covariance still creeps at T / 2 (the near-unit-root systems: there the forward filter may have
+    # converged and stopped while the backward recursion, which has not, runs on in full)
+    bound = 1e-13 if dtype == torch.float64 else 2e-6
+    for k, v in diffs.items():
+        assert v <= bound, f"{k}: default mode {v:.2e} from the literal recursion (contract {bound:.0e})"
