@@ -510,10 +510,33 @@ def main():
     device = torch.device("cuda", local_rank)
     dist = None
     ranks_seen = 1
+    transport_note = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(args.backend, device_id=device if args.backend == "nccl" else None)
+        import datetime
+        try:
+            dist.init_process_group(args.backend, device_id=device if args.backend == "nccl" else None,
+                                    timeout=datetime.timedelta(seconds=300))
+            probe = torch.ones(1, device=device)
+            dist.all_reduce(probe)  # the first collective: surface a transport that cannot run HERE, before any timing
+            torch.cuda.synchronize()
+            assert int(probe.item()) == world
+        except Exception as exc:  # noqa: BLE001 -- any failure of the requested transport
+            if args.backend == "gloo" or args.workload != "niw":
+                raise  # the sample-sharded workloads need their collective on the device transport: fail loudly
+            # The headline workload shards independent posteriors: NO data-path collective exists, only the barrier and the
+            # max-over-ranks of the timings.  Those may travel over gloo; the line says so.
+            print(f"[bench] rank {rank}: backend {args.backend} failed ({type(exc).__name__}: {str(exc)[:200]}); the timing "
+                  f"barrier / reductions of this collective-free workload fall back to gloo", file=sys.stderr, flush=True)
+            try:
+                dist.destroy_process_group()
+            except Exception:  # noqa: BLE001
+                pass
+            os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
+            transport_note = f"gloo for barrier / timing only ({args.backend} failed: {type(exc).__name__})"
+            args.backend = "gloo"
         ranks_seen = dist.get_world_size()
 
     from pyvbmp_amd import _lib
@@ -631,7 +654,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": wl.dtype_name, "data": "synthetic", "ranks_seen": ranks_seen,
-            "transport": None if world == 1 else (args.backend + (" (ranks share GPUs: rehearsal)" if args.oversubscribe else "")),
+            "transport": None if world == 1 else (transport_note or (args.backend + (" (ranks share GPUs: rehearsal)" if args.oversubscribe else ""))),
             "config": wl.config(world, args.scaling),
             "roofline": roof,
         }
