@@ -20,14 +20,23 @@ def _emission(dim, n, p, batch_shape, pad_X, X_mask, mask, device, dtype):
                                mask=mask, device=device, dtype=dtype)
 
 
-def _role_average(p, P, eta, Res):
-    """natural-parameter message to x averaged over the state posterior p (None = leave per-state)"""
+def _role_average(p, P, eta, Res, sum_axis=None):
+    """natural-parameter message to x averaged over the state posterior p (None = leave per-state).
+    sum_axis (a sample axis of p, negative, counted on p): the caller wants the messages SUMMED over that axis as well (the
+    observables of a DynamicMarkovBlanketDiscovery, ref models/DynamicMarkovBlanketDiscovery.py:98-104) with the axis kept.  A
+    precision shared by all samples is linear in the weights, so the weights are summed first: sum_obs sum_r p P_r =
+    sum_r (sum_obs p) P_r -- n_obs times less GEMM work and output (519 -> 43 MB at the flocking sizes)."""
     if p is None:
+        assert sum_axis is None
         return P, eta, Res
     w = _weight(p, 2)
-    # a precision shared by all samples (it depends on the parameters only) is averaged as one GEMM over the states
-    Pbar = shared_weighted_sum(P, p) if P.dim() == 3 and p.dim() > 1 else (P * w).sum(-3)
-    return Pbar, (eta * w).sum(-3), (Res * p).sum(-1)
+    shared = P.dim() == 3 and p.dim() > 1
+    if sum_axis is None:
+        # a precision shared by all samples (it depends on the parameters only) is averaged as one GEMM over the states
+        Pbar = shared_weighted_sum(P, p) if shared else (P * w).sum(-3)
+        return Pbar, (eta * w).sum(-3), (Res * p).sum(-1)
+    Pbar = shared_weighted_sum(P, p.sum(sum_axis, True)) if shared else (P * w).sum(-3).sum(sum_axis - 1, True)
+    return Pbar, (eta * w).sum(-3).sum(sum_axis - 1, True), (Res * p).sum(-1).sum(sum_axis + 1, True)
 
 
 class ARHMM(HMM):
@@ -77,8 +86,18 @@ class ARHMM_prXRY(HMM):
         px, R = XRY[0], XRY[1]
         Sx = px.ESigma()
         lead = torch.broadcast_shapes(Sx.shape[:-2], R.shape[:-2])
-        Sigma = torch.zeros(tuple(lead) + (self.p1 + self.p2,) * 2, device=Sx.device, dtype=Sx.dtype)
-        Sigma[..., :self.p1, :self.p1] = Sx
+        # The covariance does not depend on r: it is assembled ONCE per distinct latent message and handed on as a broadcast
+        # (stride-0) view over the remaining sample axes -- the observables of a DynamicMarkovBlanketDiscovery all see the same
+        # message, and materialising its 52 x 52 covariance for each of them was 519 MB written and re-read per iteration at
+        # the flocking sizes.  Consumers that sum over samples reduce their weights over such axes first (MatrixNormalWishart._moments).
+        keep = tuple(i for i, st in enumerate(Sx.stride()[:-2]) if not (st == 0 and Sx.shape[i] > 1))
+        Sc = Sx[tuple(slice(None) if i in keep else slice(0, 1) for i in range(Sx.ndim - 2))]
+        if self.p2 == 0:
+            Sigma_c = Sc
+        else:
+            Sigma_c = torch.zeros(tuple(Sc.shape[:-2]) + (self.p1 + self.p2,) * 2, device=Sx.device, dtype=Sx.dtype)
+            Sigma_c[..., :self.p1, :self.p1] = Sc
+        Sigma = Sigma_c.expand(tuple(lead) + (self.p1 + self.p2,) * 2)
         mu = torch.cat((px.mean().expand(tuple(lead) + (self.p1, 1)), R.expand(tuple(lead) + (self.p2, 1))), dim=-2)
         return MultivariateNormal_vector_format(mu=mu, Sigma=Sigma)
 
@@ -91,12 +110,12 @@ class ARHMM_prXRY(HMM):
     def update_obs_parms(self, XRY, lr=1.0, beta=None):
         self.obs_dist.update(self._joint_input(XRY), Delta(XRY[2]), p=self.p, lr=lr, beta=beta)
 
-    def Elog_like_X(self, YR):
-        """likelihood of x as natural parameters, averaged over the role posterior (ref :79-91)"""
+    def Elog_like_X(self, YR, sum_axis=None):
+        """likelihood of x as natural parameters, averaged over the role posterior (ref :79-91); sum_axis: see _role_average"""
         P_xr, eta_xr, Res = self.obs_dist.Elog_like_X(YR[0])
         p1, R = self.p1, YR[1]
         P = P_xr[..., :p1, :p1]
         eta = eta_xr[..., :p1, :] - shared_matvec(P_xr[..., :p1, p1:], R)
         Res = Res - 0.5 * (P_xr[..., p1:, p1:] * (R * R.transpose(-2, -1))).sum((-1, -2))
         Res = Res + (eta_xr[..., p1:, :] * R).sum((-1, -2))
-        return _role_average(self.p, P, eta, Res)
+        return _role_average(self.p, P, eta, Res, sum_axis)

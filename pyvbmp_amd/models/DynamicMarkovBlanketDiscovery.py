@@ -82,6 +82,9 @@ class DynamicMarkovBlanketDiscovery(LinearDynamicalSystems):
     def log_likelihood_function(self, Y, R):
         """natural parameters of p(y_t | x_t) averaged over the role posterior, summed over observables (ref :98-104)"""
         k = self.obs_model.event_dim + 2
+        # (the sum over the observables rides along: for the shared role precisions it is taken on the weights, before the GEMM)
+        if self.obs_model.p is not None and self.obs_model.p.ndim >= k - 1:
+            return self.obs_model.Elog_like_X((Y.unsqueeze(-k), R.unsqueeze(-k)), sum_axis=-(k - 1))
         P, eta, Res = self.obs_model.Elog_like_X((Y.unsqueeze(-k), R.unsqueeze(-k)))
         return P.sum(-k, True), eta.sum(-k, True), Res.sum(-k + 2, True)
 

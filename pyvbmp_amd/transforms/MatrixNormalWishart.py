@@ -241,9 +241,17 @@ class MatrixNormalWishart():
                 ws = None if pw is None else pw.expand(full).reshape(S)
                 return ops.weighted_matsum(Cs, ws).reshape(mat_batch + (d, d))
             if shared and pw is not None and nmb > 0:
-                Cs = C.expand(sample_shape + (1,) * nmb + (d, d)).reshape(S, d * d)
-                W = pw.expand(full).reshape(S, -1)
-                return ops.weighted_matsum_cols(Cs, W).reshape(mat_batch + (d, d))
+                Cv = C.expand(sample_shape + (1,) * nmb + (d, d))
+                Wv = pw.expand(full)
+                # sample axes along which the covariances do not vary (broadcast views, e.g. the observables of a DMBD that all
+                # see one latent message): the sum is linear in the weights, so THEY are summed over those axes first and every
+                # distinct covariance is read once
+                const = [i for i in range(nsd) if sample_shape[i] > 1 and Cv.stride(i) == 0]
+                if const:
+                    Wv = Wv.sum(const, keepdim=True)
+                    Cv = Cv[tuple(slice(0, 1) if i in const else slice(None) for i in range(nsd))]
+                S2 = int(math.prod(Cv.shape[:nsd]))
+                return ops.weighted_matsum_cols(Cv.reshape(S2, d * d), Wv.reshape(S2, -1)).reshape(mat_batch + (d, d))
             C = C.expand(full + (d, d))
             if pw is None:
                 return C.sum(tuple(range(nsd)))
