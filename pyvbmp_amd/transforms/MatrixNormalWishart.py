@@ -324,9 +324,14 @@ class MatrixNormalWishart():
             """sum_ij C_ij Pb_ij per (sample, expert); one GEMM when C is shared by the experts"""
             d = C.shape[-1]
             if nmb > 0 and C.ndim >= nmb + 2 and all(C.shape[C.ndim - 2 - nmb + i] == 1 for i in range(nmb)):
-                lead_s = tuple(C.shape[:C.ndim - 2 - nmb])
-                out = C.reshape(-1, d * d) @ Pb.reshape(-1, d * d).transpose(0, 1)
-                return out.reshape(lead_s + tuple(Pb.shape[:-2]))
+                ns = C.ndim - 2 - nmb
+                lead_s = tuple(C.shape[:ns])
+                # sample axes along which C is a broadcast view (stride 0): the trace is the same along them -- computed once on the
+                # compact covariances and expanded, instead of materialising the view for the GEMM
+                idx = tuple(slice(0, 1) if (C.stride(i) == 0 and C.shape[i] > 1) else slice(None) for i in range(ns))
+                Cc = C[idx]
+                out = Cc.reshape(-1, d * d) @ Pb.reshape(-1, d * d).transpose(0, 1)
+                return out.reshape(tuple(Cc.shape[:ns]) + tuple(Pb.shape[:-2])).expand(lead_s + tuple(Pb.shape[:-2]))
             return (C * Pb).sum((-1, -2))
         if cx is not None:
             ELL = ELL - 0.5 * trace_term(cx, P[..., :px, :px])
