@@ -63,6 +63,22 @@ def make_inputs(B, D, dtype, device, n=32, seed=0):
     return SExx, SEx, N
 
 
+class _cpu_threads:
+    """run a CPU baseline with at most n torch threads (the oracle's recursions are sequences of KB-sized batched ops: on a
+    128-thread host they run 100x SLOWER with every thread than with 8 -- 24.8 s against 0.2 s for the h = 52 smoother sample)"""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __enter__(self):
+        self.old = torch.get_num_threads()
+        torch.set_num_threads(max(1, min(self.n, self.old)))
+        return torch.get_num_threads()
+
+    def __exit__(self, *exc):
+        torch.set_num_threads(self.old)
+
+
 def _local_count(total_or_per_gpu, rank, world, scaling):
     from pyvbmp_amd.parallel import shard_bounds
     if scaling == "weak":
@@ -313,10 +329,11 @@ class LdsWorkload:
             sm = olds.smoother(lp, x0, h, yo, uo, ro, obs, 0)
             olds.latent_stats(sm, yo, uo, ro, (6,), 1, 1, (), 0)
             return time.perf_counter() - t0
-        t_small = run(16)
-        Sc = int(min(512, max(16, 16 * target_s / 2.0 / max(t_small, 1e-3))))
-        best = run(Sc)
-        return {"value": T * Sc / best, "unit": self.unit, "cores": torch.get_num_threads(), "kind": "port",
+        with _cpu_threads(8) as nthreads:
+            t_small = run(16)
+            Sc = int(min(512, max(16, 16 * target_s / 2.0 / max(t_small, 1e-3))))
+            best = run(Sc)
+        return {"value": T * Sc / best, "unit": self.unit, "cores": nthreads, "kind": "port",
                 "sample": f"oracle.lds.smoother + latent_stats (fp64) on T={T}, {Sc} series of the same Lorenz data, {best:.2f} s; "
                           f"host has {os.cpu_count()} logical cpus"}
 
@@ -411,15 +428,16 @@ class DmbdWorkload:
             t0 = time.perf_counter()
             olds.smoother(lp, x0, h, yo, uo, ro, None, 0, like=(P, eta, res))
             return time.perf_counter() - t0
-        t_small = run(2)
-        Sc = int(min(20, max(2, 2 * target_s / 2.0 / max(t_small, 1e-3))))
-        best = run(Sc)
+        with _cpu_threads(8) as nthreads:
+            t_small = run(2)
+            Sc = int(min(20, max(2, 2 * target_s / 2.0 / max(t_small, 1e-3))))
+            best = run(Sc)
         ref_s = (1.05, 3.8)  # DynamicMarkovBlanketDiscovery.update, Flocking hyper-parameters, (30, 4, 12, 4) fp32
         return {"value": 30 * 4 / ref_s[0], "unit": self.unit, "cores": 8,
                 "kind": "reference (quoted from BASELINE.md 2: survey container, 8 threads; not re-timed on this host)",
                 "sample": f"DynamicMarkovBlanketDiscovery.update of the imported reference at these hyper-parameters on (T=30, 4 series, 12 "
                           f"observables) fp32: {ref_s[0]}-{ref_s[1]} s per iteration, best case quoted",
-                "port_smoother": {"value": T * Sc / best, "unit": self.unit, "cores": torch.get_num_threads(), "kind": "port",
+                "port_smoother": {"value": T * Sc / best, "unit": self.unit, "cores": nthreads, "kind": "port",
                                   "sample": f"oracle.lds.smoother (fp64) at hidden {h}, one likelihood precision per (t, series), T={T}, {Sc} "
                                             f"series: {best:.2f} s -- the smoother alone, not the iteration; host has {os.cpu_count()} logical cpus"}}
 

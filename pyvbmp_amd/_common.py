@@ -80,6 +80,17 @@ def shared_weighted_sum(P, w):
     return (w.reshape(-1, R) @ P.reshape(R, a * b)).reshape(tuple(w.shape[:-1]) + (a, b))
 
 
+def shared_weighted_matvec(A, v, w):
+    """sum_r w[..., r] * (A[r] @ v[...]) for SHARED matrices A ((R, n, k), no sample axes), per-sample vectors v (sample + (k, 1)) and
+    per-sample weights w (sample + (R,)): ONE (samples, R k) x (R k, n) GEMM on the features w (x) v, instead of the per-state products
+    (samples, R, n) and their weighted sum (250 MB each way for the role-averaged message of the flocking DMBD).  Returns sample + (n, 1)."""
+    R, n, k = A.shape
+    lead = tuple(torch.broadcast_shapes(v.shape[:-2], w.shape[:-1]))
+    f = (w.expand(lead + (R,)).unsqueeze(-1) * v.expand(lead + (k, 1)).squeeze(-1).unsqueeze(-2)).reshape(-1, R * k)
+    out = f @ A.transpose(-2, -1).reshape(R * k, n)
+    return out.reshape(lead + (n, 1))
+
+
 def rows_matmul(X, W):
     """X @ W for X = lead + (k,) with very many rows and ONE small W (k, n): K12 (one streaming pass) on the device when
     the library GEMM would be the tall-skinny case it handles poorly (_k12_pays); `@` otherwise."""

@@ -3,7 +3,7 @@ reference's models/ARHMM.py:13-91).  ARHMM_prXRY is the role model of DynamicMar
 (a Gaussian message), observed regressors r and observed outputs y."""
 import torch
 
-from .._common import shared_matvec, shared_weighted_sum
+from .._common import shared_matvec, shared_weighted_matvec, shared_weighted_sum
 from ..dists.Delta import Delta
 from ..dists.MultivariateNormal_vector_format import MultivariateNormal_vector_format
 from ..transforms.MatrixNormalWishart import MatrixNormalWishart
@@ -112,8 +112,27 @@ class ARHMM_prXRY(HMM):
 
     def Elog_like_X(self, YR, sum_axis=None):
         """likelihood of x as natural parameters, averaged over the role posterior (ref :79-91); sum_axis: see _role_average"""
+        B, p1, R = self.obs_dist, self.p1, YR[1]
+        if self.p is not None and not B.pad_X and B.batch_dim == 1 and B.event_dim == 2 and self.p.dim() > 1 and YR[0].is_cuda:
+            # Role-averaged message without the per-role intermediates: the precision and the linear term are linear in the role
+            # weights, so sum_r p_r (G_r' y) is ONE GEMM on the features p (x) y (shared_weighted_matvec) and sum_r p_r H_r one GEMM on
+            # p (summed over `sum_axis` first) -- the per-(sample, role) message (samples x 25 x 52) is never formed
+            H, Gt = B.EXTinvUX(), B.EXTinvU()  # (roles, p, p), (roles, p, n)
+            k = -1 - B.event_dim                # the role axis of the samples
+            Y = YR[0].squeeze(k)
+            Rs = R.squeeze(k)
+            eta = shared_weighted_matvec(Gt[..., :p1, :], Y, self.p)
+            Res = B._residual_y(YR[0])
+            if self.p2 > 0:
+                eta = eta - shared_weighted_matvec(H[..., :p1, p1:], Rs, self.p)
+                Res = Res - 0.5 * (H[..., p1:, p1:] * (R * R.transpose(-2, -1))).sum((-1, -2))
+                Res = Res + (shared_matvec(Gt[..., p1:, :], YR[0]) * R).sum((-1, -2))
+            Res = (Res * self.p).sum(-1)
+            Hxx = H[..., :p1, :p1]
+            if sum_axis is None:
+                return shared_weighted_sum(Hxx, self.p), eta, Res
+            return (shared_weighted_sum(Hxx, self.p.sum(sum_axis, True)), eta.sum(sum_axis - 1, True), Res.sum(sum_axis + 1, True))
         P_xr, eta_xr, Res = self.obs_dist.Elog_like_X(YR[0])
-        p1, R = self.p1, YR[1]
         P = P_xr[..., :p1, :p1]
         eta = eta_xr[..., :p1, :] - shared_matvec(P_xr[..., :p1, p1:], R)
         Res = Res - 0.5 * (P_xr[..., p1:, p1:] * (R * R.transpose(-2, -1))).sum((-1, -2))

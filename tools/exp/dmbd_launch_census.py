@@ -31,6 +31,11 @@ def census(name, fn):
     print(f"== {name}: {len(ks)} device activities, {tot:.2f} ms of device time, {wall:.2f} ms wall (unprofiled)")
     for k, v in c.most_common(6):
         print(f"   {v:4d} {k}")
+    tm = collections.Counter()
+    for ev in ks:
+        tm[ev.name[:90]] += (ev.device_time if hasattr(ev, "device_time") else ev.cuda_time) / 1e3
+    for k, v in tm.most_common(8):
+        print(f"   {v:7.3f} ms  {k}")
 
 
 census("update_assignments", lambda: m.update_assignments(yy, rr))
