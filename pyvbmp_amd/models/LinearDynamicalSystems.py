@@ -305,6 +305,8 @@ class LinearDynamicalSystems():
         QA = self.A.EinvUX()
         self.QA_xp_x = QA[..., :, :h].contiguous()
         self.QA_xp_u = QA[..., :, h:]
+        # E log|invQ|: a function of the transition's noise parameters like the blocks above (six launches per E-step otherwise)
+        self.A_Elogdet = self.A.ElogdetinvSigma()
 
     def log_likelihood_function(self, Y, R):
         """natural parameters of the likelihood of x_t (ref :244-266)"""
@@ -391,7 +393,7 @@ class LinearDynamicalSystems():
         x0_P, x0_eta, x0_res = x0.mixture_estep_params()
         if h <= ops.L.LDS_MAX_H or (h <= ops.L.LDS_MAX_H_BLOCK and ops.L.lds_block_fits(h, y.element_size())):
             out = ops.lds_smoother(T_max, sample_shape, bo_shape, h, self.invQ, self.ATQA_x_x, self.QA_xp_x,
-                                   self.A.ElogdetinvSigma(), x0_P, x0_eta, x0_res,
+                                   self.A_Elogdet, x0_P, x0_eta, x0_res,
                                    invSigma_like, invSigmamu_like.squeeze(-1), Residual_like, cu1, cu2, cu3,
                                    sums_only=sums_only, y=y.squeeze(-1) if (sums_only and len(self.offset) == 0) else None,
                                    fixed_point=self.fixed_point if fixed_point is None else fixed_point)
@@ -416,7 +418,7 @@ class LinearDynamicalSystems():
         kw = {"device": eta_like.device, "dtype": eta_like.dtype}
         invQ, ATQA, QA = self.invQ, self.ATQA_x_x, self.QA_xp_x
         QAT = _T(QA)
-        AEl = self.A.ElogdetinvSigma()
+        AEl = self.A_Elogdet
         x0P, x0e = self.x0.EinvSigma(), self.x0.EinvSigmamu()
 
         def at(X, t, inner):  # time slice of an operand that may not depend on time

@@ -23,6 +23,12 @@ def census(name, fn):
     print(f"== {name}: {len(ks)} device activities")
     for k, v in c.most_common(12):
         print(f"   {v:3d} {k}")
+    tm = collections.Counter()
+    for ev in ks:
+        tm[ev.name[:80]] += (ev.device_time if hasattr(ev, "device_time") else ev.cuda_time) / 1e3
+    print(f"   device time {sum(tm.values()):.3f} ms:")
+    for k, v in tm.most_common(10):
+        print(f"   {v:7.3f} ms  {k}")
 
 
 om, x0, A = m.obs_model, m.x0, m.A
