@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VBMP_ABI_VERSION 6
+#define VBMP_ABI_VERSION 7
 int vbmp_abi_version(void);
 
 /* K1 -- Ainv = A^-1 and logdet = log det A of B symmetric positive definite matrices.
@@ -307,6 +307,15 @@ int vbmp_niw_estep_params_f64(const double* U, const double* nu, const double* m
                               const double* alpha, int64_t K, int D, double* P, double* b, double* c, void* stream);
 int vbmp_niw_estep_params_f32(const float* U, const float* nu, const float* mu, const float* lam, const float* logdet_invU,
                               const float* alpha, int64_t K, int D, float* P, float* b, float* c, void* stream);
+/* K14 -- the expectations of a MatrixNormalWishart posterior that its messages and likelihoods read, in one launch (the getters
+ * MatrixNormalWishart.EinvSigma / EinvUX / EXTinvU / EXTinvUX / ElogdetinvSigma, transforms/MatrixNormalWishart.py:419-471 with
+ * dists/Wishart.py:67-83), for NB batch elements of an (n x p) transform:
+ *     R = U nu (n,n);  G = R mu (n,p) [EXTinvU = G'];  H = n V + mu' G (p,p);  El = sum_{i<n} psi((nu - i)/2) + n log 2 - logdet_invU.
+ * All dense: mu (NB,n,p), U (NB,n,n), nu / logdet_invU (NB), V (NB,p,p); outputs R (NB,n,n), G (NB,n,p), H (NB,p,p), El (NB). */
+int vbmp_mnw_expectations_f64(const double* mu, const double* U, const double* nu, const double* V, const double* logdet_invU,
+                              int64_t NB, int n, int p, double* R, double* G, double* H, double* El, void* stream);
+int vbmp_mnw_expectations_f32(const float* mu, const float* U, const float* nu, const float* V, const float* logdet_invU, int64_t NB,
+                              int n, int p, float* R, float* G, float* H, float* El, void* stream);
 /* K12 with the observation likelihood's scalar in the same pass: additionally q[s] = -1/2 x' P x + b' x + c0[0]
  * (LinearDynamicalSystems.log_likelihood_function, models/LinearDynamicalSystems.py:244-266: invSigmamu_t and Residual of
  * every (time, series) from ONE read of the observations).  P dense (k,k); b (k) or NULL; c0 one element in device memory or

@@ -2,6 +2,17 @@
 import torch
 
 
+# Derived quantities cached on a parameter object (MatrixNormalWishart's expectations, K14) are keyed by the identity and version
+# of the tensors they were computed from -- and by this epoch, which graph.GraphedStep advances whenever a replayed graph has
+# rewritten state tensors in place behind Python's back (a replay bumps no tensor version).
+state_epoch = [0]
+
+
+def derived_key(*tensors):
+    cap = tensors[0].is_cuda and torch.cuda.is_current_stream_capturing()
+    return (state_epoch[0], cap) + tuple((id(t), t._version) for t in tensors)
+
+
 def resolve(device=None, dtype=None):
     """Device / dtype for freshly created state.  The reference has no device plumbing (it relies on
     torch defaults), so the defaults follow torch.set_default_device / set_default_dtype."""

@@ -16,7 +16,7 @@ _c_i64 = ctypes.c_int64
 _c_int = ctypes.c_int
 _c_ptr = ctypes.c_void_p
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lib = None
 
@@ -145,6 +145,8 @@ SYMBOLS = {
     "vbmp_rows_affine": _sig_rows,
     # U, nu, mu, lam, logdet_invU, alpha, K, D, P, b, c, stream
     "vbmp_niw_estep_params": lambda T: [_c_ptr] * 6 + [_c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
+    # mu, U, nu, V, logdet_invU, NB, n, p, R, G, H, El, stream
+    "vbmp_mnw_expectations": lambda T: [_c_ptr] * 5 + [_c_i64, _c_int, _c_int] + [_c_ptr] * 5,
     # X, S, k, M, c, n, out, P, b, c0, q, stream
     "vbmp_rows_affine_quad": lambda T: [_c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
 }

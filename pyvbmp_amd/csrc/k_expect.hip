@@ -75,6 +75,58 @@ __global__ __launch_bounds__(64) void k_niw_estep_params(const T* __restrict__ U
   }
 }
 
+// K14: the expectations of a MatrixNormalWishart posterior that its messages and likelihoods read
+// (ref transforms/MatrixNormalWishart.py:419-471 with dists/Wishart.py:67-83), for NB batch elements of an (n x p) transform:
+//     R = E[Sigma^-1] = U nu                    (n x n)        EinvSigma
+//     G = R mu                                  (n x p)        EinvUX        (EXTinvU is its transpose)
+//     H = n V + mu' R mu = n V + mu' G          (p x p)        EXTinvUX
+//     El = sum_{i<n} psi((nu - i) / 2) + n log 2 - logdet_invU                ElogdetinvSigma
+// One block per batch element; composed from the getters this is 14 launches wherever a caller asks for them.
+template <typename T>
+__global__ __launch_bounds__(256) void k_mnw_expectations(const T* __restrict__ mu, const T* __restrict__ U, const T* __restrict__ nu,
+                                                          const T* __restrict__ V, const T* __restrict__ logdet_invU, int n, int p,
+                                                          T* __restrict__ R, T* __restrict__ G, T* __restrict__ H, T* __restrict__ El) {
+  const int64_t b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const T nub = nu[b];
+  const T* mub = mu + b * (int64_t)n * p;
+  const T* Ub = U + b * (int64_t)n * n;
+  const T* Vb = V + b * (int64_t)p * p;
+  T* Rb = R + b * (int64_t)n * n;
+  T* Gb = G + b * (int64_t)n * p;
+  T* Hb = H + b * (int64_t)p * p;
+  for (int e = tid; e < n * n; e += 256) Rb[e] = Ub[e] * nub;
+  for (int e = tid; e < n * p; e += 256) {
+    const int i = e / p, c = e - i * p;
+    T acc = T(0);
+    for (int k = 0; k < n; ++k) acc += (Ub[i * n + k] * nub) * mub[k * p + c];
+    Gb[e] = acc;
+  }
+  __syncthreads();  // G of this block is complete (and visible to the block)
+  for (int e = tid; e < p * p; e += 256) {
+    const int a = e / p, c = e - a * p;
+    T acc = T(0);
+    for (int i = 0; i < n; ++i) acc += mub[i * p + a] * Gb[i * p + c];
+    Hb[e] = (T)n * Vb[e] + acc;
+  }
+  if (tid < 64) {
+    double ps = 0.0;
+    for (int i = tid; i < n; i += 64) ps += digamma_pos(0.5 * ((double)nub - (double)i));
+    ps = wave_sum(ps);
+    if (tid == 0) El[b] = (T)(ps + (double)n * 0.693147180559945309417232121458 - (double)logdet_invU[b]);
+  }
+}
+
+template <typename T>
+static int mnw_expectations_dispatch(const T* mu, const T* U, const T* nu, const T* V, const T* logdet_invU, int64_t NB, int n, int p,
+                                     T* R, T* G, T* H, T* El, void* stream) {
+  if (NB == 0) return 0;
+  if (!mu || !U || !nu || !V || !logdet_invU || !R || !G || !H || !El || NB < 0 || NB > 0x7fffffff || n < 1 || p < 1) return VBMP_ERR_ARG;
+  hipLaunchKernelGGL((k_mnw_expectations<T>), dim3((unsigned)NB), dim3(256), 0, (hipStream_t)stream, mu, U, nu, V, logdet_invU, n, p, R, G,
+                     H, El);
+  return hipGetLastError() == hipSuccess ? 0 : VBMP_ERR_LAUNCH;
+}
+
 template <typename T>
 static int niw_estep_params_dispatch(const T* U, const T* nu, const T* mu, const T* lam, const T* logdet_invU, const T* alpha,
                                      int64_t K, int D, T* P, T* b, T* c, void* stream) {
@@ -91,6 +143,14 @@ extern "C" {
 int vbmp_niw_estep_params_f64(const double* U, const double* nu, const double* mu, const double* lam, const double* logdet_invU,
                               const double* alpha, int64_t K, int D, double* P, double* b, double* c, void* stream) {
   return vbmp::niw_estep_params_dispatch<double>(U, nu, mu, lam, logdet_invU, alpha, K, D, P, b, c, stream);
+}
+int vbmp_mnw_expectations_f64(const double* mu, const double* U, const double* nu, const double* V, const double* logdet_invU,
+                              int64_t NB, int n, int p, double* R, double* G, double* H, double* El, void* stream) {
+  return vbmp::mnw_expectations_dispatch<double>(mu, U, nu, V, logdet_invU, NB, n, p, R, G, H, El, stream);
+}
+int vbmp_mnw_expectations_f32(const float* mu, const float* U, const float* nu, const float* V, const float* logdet_invU, int64_t NB,
+                              int n, int p, float* R, float* G, float* H, float* El, void* stream) {
+  return vbmp::mnw_expectations_dispatch<float>(mu, U, nu, V, logdet_invU, NB, n, p, R, G, H, El, stream);
 }
 int vbmp_niw_estep_params_f32(const float* U, const float* nu, const float* mu, const float* lam, const float* logdet_invU,
                               const float* alpha, int64_t K, int D, float* P, float* b, float* c, void* stream) {

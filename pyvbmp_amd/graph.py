@@ -21,6 +21,8 @@ import weakref
 
 import torch
 
+from ._common import state_epoch
+
 # Destroying a HIP graph while a stream is capturing aborts the process.  Graphs therefore never die during a capture:
 # (1) a GraphedStep holds its model only weakly and gets the model passed into its step function, so there is no
 # model -> cache -> GraphedStep -> closure -> model cycle and a graph's lifetime ends deterministically with its model
@@ -112,6 +114,7 @@ class GraphedStep():
         gc_was_on = gc.isenabled()
         gc.disable()
         _capture_depth += 1
+        state_epoch[0] += 1
         try:
             self._capture(model, step, before, static)
         finally:
@@ -123,6 +126,7 @@ class GraphedStep():
         self.static = static
         self.iterations = warmup + 1  # the capture pass does not execute; accounted for by the first replay below
         self.graph.replay()
+        state_epoch[0] += 1
         if post is not None:
             post()
 
@@ -193,6 +197,7 @@ class GraphedStep():
     def run(self, iters=1):
         for _ in range(iters):
             self.graph.replay()
+            state_epoch[0] += 1  # the replay rewrote state in place: quantities cached from it are stale
             self._run_post()
         self.iterations += iters
         return self

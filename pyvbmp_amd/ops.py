@@ -639,6 +639,28 @@ def niw_estep_params(U, nu, mu, lam, logdet_invU, alpha=None):
     return P, b, c
 
 
+def mnw_expectations(mu, U, nu, V, logdet_invU):
+    """K14: (EinvSigma, EinvUX, EXTinvUX, ElogdetinvSigma) of a MatrixNormalWishart posterior, one launch.  mu: lead + (n, p),
+    U: lead + (n, n), nu / logdet_invU: lead, V: lead + (p, p) (operands may be broadcast over lead)."""
+    dev = L.require_device(mu, U, nu, V, logdet_invU)
+    lib = L.load()
+    dt = mu.dtype
+    lead = tuple(mu.shape[:-2])
+    n, p = mu.shape[-2:]
+    NB = _prod(lead)
+    ins = [mu.reshape(NB, n, p).contiguous(), U.to(dt).expand(lead + (n, n)).reshape(NB, n, n).contiguous(),
+           nu.to(dt).expand(lead).reshape(NB).contiguous(), V.to(dt).expand(lead + (p, p)).reshape(NB, p, p).contiguous(),
+           logdet_invU.to(dt).expand(lead).reshape(NB).contiguous()]
+    R = torch.empty(lead + (n, n), dtype=dt, device=dev)
+    G = torch.empty(lead + (n, p), dtype=dt, device=dev)
+    H = torch.empty(lead + (p, p), dtype=dt, device=dev)
+    El = torch.empty(lead, dtype=dt, device=dev)
+    if NB > 0:
+        fn = getattr(lib, "vbmp_mnw_expectations_" + L.suffix(dt))
+        L.call(fn, "vbmp_mnw_expectations", *[L.ptr(t) for t in ins], NB, n, p, L.ptr(R), L.ptr(G), L.ptr(H), L.ptr(El), L.stream_ptr(dev))
+    return R, G, H, El
+
+
 MATSUM_MAX_COLS = 32
 
 

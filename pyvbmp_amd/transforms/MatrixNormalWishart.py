@@ -16,7 +16,7 @@ import math
 import torch
 
 from .. import ops
-from .._common import as_param, resolve, shared_matvec
+from .._common import as_param, derived_key, resolve, shared_matvec
 from ..dists.MultivariateNormal_vector_format import MultivariateNormal_vector_format
 from ..dists.Wishart import Wishart
 from ..utils.matrix_utils import matrix_utils
@@ -494,11 +494,28 @@ class MatrixNormalWishart():
     def var(self):
         return self.ESigma().diagonal(dim1=-1, dim2=-2).unsqueeze(-1) * self.V.diagonal(dim1=-1, dim2=-2).unsqueeze(-2)
 
+    def _expectations(self):
+        """(EinvSigma, EinvUX, EXTinvUX, ElogdetinvSigma) from ONE launch (K14), kept until a tensor they were computed from is
+        rebound or written (composed from the getters: 14 launches wherever a caller asks for them); None where the noise model is
+        not a plain Wishart (the diagonal sibling overrides the getters) or the state is not on the GPU.  Callers treat the
+        returned tensors as read-only."""
+        W = self.invU
+        if type(W) is not Wishart or not self.mu.is_cuda:
+            return None
+        src = (self.mu, W.U, W.nu, self.V, W.logdet_invU)
+        key = derived_key(*src)
+        c = self.__dict__.get("_vbmp_expect")
+        if c is None or c[0] != key:
+            c = self._vbmp_expect = (key, ops.mnw_expectations(*src), src)  # src kept alive: ids stay unique
+        return c[1]
+
     def EinvUX(self):
-        return self.invU.EinvSigma() @ self.mu
+        e = self._expectations()
+        return e[1] if e is not None else self.invU.EinvSigma() @ self.mu
 
     def EXTinvU(self):
-        return _T(self.mu) @ self.invU.EinvSigma()
+        e = self._expectations()
+        return _T(e[1]) if e is not None else _T(self.mu) @ self.invU.EinvSigma()
 
     def EXTAX(self, A):
         return self.V * (self.invU.ESigma() * A).sum((-1, -2)) + _T(self.mu) @ A @ self.mu
@@ -513,7 +530,8 @@ class MatrixNormalWishart():
         return self.ESigma() * (self.V * A).sum((-1, -2))
 
     def EXTinvUX(self):
-        return self.n * self.V + _T(self.mu) @ self.invU.EinvSigma() @ self.mu
+        e = self._expectations()
+        return e[2] if e is not None else self.n * self.V + _T(self.mu) @ self.invU.EinvSigma() @ self.mu
 
     def EXinvVXT(self):
         return self.p * self.invU.ESigma() + self.mu @ self.invV @ _T(self.mu)
@@ -537,10 +555,12 @@ class MatrixNormalWishart():
         return self.invU.logdetEinvSigma()
 
     def ElogdetinvSigma(self):
-        return self.invU.ElogdetinvSigma()
+        e = self._expectations()
+        return e[3] if e is not None else self.invU.ElogdetinvSigma()
 
     def EinvSigma(self):
-        return self.invU.EinvSigma()
+        e = self._expectations()
+        return e[0] if e is not None else self.invU.EinvSigma()
 
     def invEinvSigma(self):
         return self.invU.invEinvSigma()

@@ -388,3 +388,70 @@ def test_mnw_messages_full_size_fp32_properties(golden):
     assert_close(Q[idx], P_o, 1e-4, what="bw P sample")
     assert_close(pX.invSigmamu[idx], e_o, 1e-4, what="bw eta sample")
     assert_close(Rb[idx], Rb_o, 1e-4, what="bw Res sample")
+
+
+def _composed_expectations(m):
+    """the five getters composed from the Wishart's own (ref transforms/MatrixNormalWishart.py:419-471)"""
+    R = m.invU.EinvSigma()
+    return R, R @ m.mu, m.n * m.V + m.mu.mT @ R @ m.mu, m.invU.ElogdetinvSigma()
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("event, batch, pad, masked", [((3, 2), (), False, False), ((6, 6), (), True, False),
+                                                       ((4, 5), (7,), True, False), ((2, 3, 4), (5,), False, False),
+                                                       ((6, 6), (3,), True, True), ((33, 40), (2,), False, False)])
+def test_mnw_expectations_one_launch(event, batch, pad, masked, dtype):
+    """K14: EinvSigma / EinvUX / EXTinvU / EXTinvUX / ElogdetinvSigma from one launch == the composed getters, and the cached
+    values follow every way the parameters can change (rebinding by an update, in-place writes, a replayed graph)."""
+    from pyvbmp_amd.transforms.MatrixNormalWishart import MatrixNormalWishart
+    torch.manual_seed(5)
+    tol = dict(tol=1e-12) if dtype == torch.float64 else dict(tol=2e-5)
+    mask = None
+    if masked:
+        mask = torch.rand(event, device="cuda") > 0.3  # event-shaped, shared by the batch
+    m = MatrixNormalWishart(event, batch, pad_X=pad, mask=mask, device="cuda", dtype=dtype)
+    n, p = m.n, m.p
+    px = p - 1 if pad else p
+    lead = batch + tuple(event[:-2])
+
+    def check():
+        want = _composed_expectations(m)
+        got = (m.EinvSigma(), m.EinvUX(), m.EXTinvUX(), m.ElogdetinvSigma())
+        for g, w in zip(got, want):
+            assert g.shape == w.shape
+            assert_close(g, w, **tol)
+        assert_close(m.EXTinvU(), want[1].mT, **tol)
+
+    check()
+    assert m._expectations() is not None and m.EinvSigma() is m.EinvSigma()  # served from the cache
+    for _ in range(2):  # an update rebinds the parameters
+        X = torch.randn((50,) + (1,) * len(lead) + (px, 1), device="cuda", dtype=dtype)
+        Y = torch.randn((50,) + lead + (n, 1), device="cuda", dtype=dtype)
+        m.raw_update(X, Y, lr=0.7)
+        check()
+    m.mu.mul_(1.5)  # an in-place write bumps the tensor's version
+    check()
+    m.invU.nu.add_(2.0)
+    check()
+
+
+def test_mnw_expectations_cache_follows_graph_replays():
+    """a replayed HIP graph rewrites the parameters in place without touching any tensor version: the graph advances the state
+    epoch, so getters read eagerly between replays are recomputed"""
+    from pyvbmp_amd import graph
+    from pyvbmp_amd.transforms.MatrixNormalWishart import MatrixNormalWishart
+    torch.manual_seed(6)
+    m = MatrixNormalWishart((4, 3), (), pad_X=True, device="cuda", dtype=torch.float64)
+    ref = MatrixNormalWishart((4, 3), (), pad_X=True, device="cuda", dtype=torch.float64)
+    for k in ("mu", "mu_0"):
+        setattr(ref, k, getattr(m, k).clone())
+    X = torch.randn(200, 3, 1, device="cuda", dtype=torch.float64)
+    Y = torch.randn(200, 4, 1, device="cuda", dtype=torch.float64)
+    seen = []
+    g = graph.GraphedStep(m, lambda mm: mm.raw_update(X, Y, lr=0.5), warmup=1, post=lambda mm: seen.append(mm.EXTinvUX().clone()))
+    g.run(3)
+    for i in range(5):
+        ref.raw_update(X, Y, lr=0.5)
+        assert_close(seen[i], _composed_expectations(ref)[2], tol=1e-10)
+    assert_close(m.EinvUX(), _composed_expectations(ref)[1], tol=1e-10)
+    g.close()
