@@ -19,6 +19,28 @@ __global__ __launch_bounds__(256) void k_fma4(double* o, double a, double b) {  
   }
   o[threadIdx.x] = x0 + x1 + x2 + x3;
 }
+// scalar instructions beside vector ones: do they take issue slots of a lone wave?  NS s_mul_i32 per v_fma_f64 (4 independent chains)
+template <int NS>
+__global__ __launch_bounds__(256) void k_fma4_salu(double* o, double a, double b, int seed) {
+  double x0 = o[threadIdx.x], x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3;
+  int s0 = seed, s1 = seed + 1, s2 = seed + 2, s3 = seed + 3;
+#pragma unroll 4
+  for (int i = 0; i < N; ++i) {
+    x0 = __builtin_fma(x0, a, b);
+    if (NS >= 1) asm volatile("s_mul_i32 %0, %0, %1" : "+s"(s0) : "s"(seed) : "scc");
+    if (NS >= 2) asm volatile("s_mul_i32 %0, %0, %1" : "+s"(s1) : "s"(seed) : "scc");
+    x1 = __builtin_fma(x1, a, b);
+    if (NS >= 3) asm volatile("s_mul_i32 %0, %0, %1" : "+s"(s2) : "s"(seed) : "scc");
+    if (NS >= 4) asm volatile("s_mul_i32 %0, %0, %1" : "+s"(s3) : "s"(seed) : "scc");
+    x2 = __builtin_fma(x2, a, b);
+    if (NS >= 1) asm volatile("s_add_u32 %0, %0, %1" : "+s"(s0) : "s"(seed) : "scc");
+    if (NS >= 2) asm volatile("s_add_u32 %0, %0, %1" : "+s"(s1) : "s"(seed) : "scc");
+    x3 = __builtin_fma(x3, a, b);
+    if (NS >= 3) asm volatile("s_add_u32 %0, %0, %1" : "+s"(s2) : "s"(seed) : "scc");
+    if (NS >= 4) asm volatile("s_add_u32 %0, %0, %1" : "+s"(s3) : "s"(seed) : "scc");
+  }
+  o[threadIdx.x] = x0 + x1 + x2 + x3 + (double)(s0 + s1 + s2 + s3);
+}
 __global__ __launch_bounds__(256) void k_rcp(double* o) {
   double x = o[threadIdx.x];
 #pragma unroll 8
@@ -111,9 +133,11 @@ int main() {
   std::vector<double> h(1 << 17, 1.0000001);
   hipMemcpy(d, h.data(), 1 << 20, hipMemcpyHostToDevice);
   hipMemset(f, 0, 1 << 20);
-  for (int nblk : {1, 40, 256}) {
+  for (int nblk : {40, 256}) {
     run("dependent v_fma_f64", [&](int n) { hipLaunchKernelGGL(k_fma, dim3(n), dim3(256), 0, 0, d, 1.0000001, 1e-9); }, nblk);
     run("4 independent v_fma_f64 chains", [&](int n) { hipLaunchKernelGGL(k_fma4, dim3(n), dim3(256), 0, 0, d, 1.0000001, 1e-9); }, nblk);
+    run("4 fma chains + 4 salu per 4 fma", [&](int n) { hipLaunchKernelGGL(k_fma4_salu<2>, dim3(n), dim3(256), 0, 0, d, 1.0000001, 1e-9, 3); }, nblk);
+    run("4 fma chains + 8 salu per 4 fma", [&](int n) { hipLaunchKernelGGL(k_fma4_salu<4>, dim3(n), dim3(256), 0, 0, d, 1.0000001, 1e-9, 3); }, nblk);
     run("dependent v_fma_f32", [&](int n) { hipLaunchKernelGGL(k_fmaf, dim3(n), dim3(256), 0, 0, f, 1.0000001f, 1e-9f); }, nblk);
     run("dependent v_rcp_f64", [&](int n) { hipLaunchKernelGGL(k_rcp, dim3(n), dim3(256), 0, 0, d); }, nblk);
     run("LDS write/sync/read (wave)", [&](int n) { hipLaunchKernelGGL(k_lds, dim3(n), dim3(256), 0, 0, d); }, nblk);
