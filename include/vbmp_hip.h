@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VBMP_ABI_VERSION 7
+#define VBMP_ABI_VERSION 8
 int vbmp_abi_version(void);
 
 /* K1 -- Ainv = A^-1 and logdet = log det A of B symmetric positive definite matrices.
@@ -316,6 +316,35 @@ int vbmp_mnw_expectations_f64(const double* mu, const double* U, const double* n
                               int64_t NB, int n, int p, double* R, double* G, double* H, double* El, void* stream);
 int vbmp_mnw_expectations_f32(const float* mu, const float* U, const float* nu, const float* V, const float* logdet_invU, int64_t NB,
                               int n, int p, float* R, float* G, float* H, float* El, void* stream);
+/* K15 -- KL(q || prior) of the conjugate families, one launch each (12-40 launches each when composed from element-wise kernels,
+ * lgamma / digamma and reductions; every model's ELBO sums them once per VB iteration).  One result per batch element, NB of them;
+ * posterior operands dense; every PRIOR operand comes with its batch stride in elements (0 = one prior shared by the batch, the
+ * reference's expanded priors).
+ *   dirichlet_kl : Dirichlet.KLqprior (dists/Dirichlet.py:73-86), K = entries per event; structural zeros count as 0 like the
+ *                  reference's KL_lgamma / KL_digamma.
+ *   gamma_kl     : Gamma.KLqprior (dists/Gamma.py:66-72) summed over the K entries of an event (DiagonalWishart.KLqprior).
+ *   wishart_kl   : Wishart.KLqprior (dists/Wishart.py:85-95) for n x n; with mu != NULL also the Normal part of
+ *                  NormalInverseWishart.KLqprior (dists/NormalInverseWishart.py:134-141): mu / mu0 (NB, n), lam / lam0 (NB).
+ *   mn_kl        : the matrix-normal part of MatrixNormalWishart / MatrixNormalGamma.KLqprior (transforms/MatrixNormalWishart.py:
+ *                  206-215, MatrixNormalGamma.py:203-214) for an (n x p) transform: R = E[invSigma] (NB, n, n), xm = number of set
+ *                  entries of X_mask (0 without one); n p <= 8192. */
+int vbmp_dirichlet_kl_f64(const double* alpha, const double* alpha0, int64_t s0, int64_t NB, int K, double* out, void* stream);
+int vbmp_dirichlet_kl_f32(const float* alpha, const float* alpha0, int64_t s0, int64_t NB, int K, float* out, void* stream);
+int vbmp_gamma_kl_f64(const double* alpha, const double* beta, const double* alpha0, const double* beta0, int64_t sa0, int64_t sb0,
+                      int64_t NB, int K, double* out, void* stream);
+int vbmp_gamma_kl_f32(const float* alpha, const float* beta, const float* alpha0, const float* beta0, int64_t sa0, int64_t sb0,
+                      int64_t NB, int K, float* out, void* stream);
+int vbmp_wishart_kl_f64(const double* invU0, int64_t sm0, const double* U, const double* nu, const double* nu0, int64_t sn0,
+                        const double* ld, const double* ld0, int64_t sl0, const double* mu, const double* mu0, int64_t smu0,
+                        const double* lam, const double* lam0, int64_t slam0, int64_t NB, int n, double* out, void* stream);
+int vbmp_wishart_kl_f32(const float* invU0, int64_t sm0, const float* U, const float* nu, const float* nu0, int64_t sn0,
+                        const float* ld, const float* ld0, int64_t sl0, const float* mu, const float* mu0, int64_t smu0,
+                        const float* lam, const float* lam0, int64_t slam0, int64_t NB, int n, float* out, void* stream);
+int vbmp_mn_kl_f64(const double* mu, const double* mu0, int64_t smu0, const double* invV0, int64_t sv0, const double* V,
+                   const double* R, const double* ldV, const double* ldV0, int64_t sl0, double xm, int64_t NB, int n, int p,
+                   double* out, void* stream);
+int vbmp_mn_kl_f32(const float* mu, const float* mu0, int64_t smu0, const float* invV0, int64_t sv0, const float* V, const float* R,
+                   const float* ldV, const float* ldV0, int64_t sl0, double xm, int64_t NB, int n, int p, float* out, void* stream);
 /* K12 with the observation likelihood's scalar in the same pass: additionally q[s] = -1/2 x' P x + b' x + c0[0]
  * (LinearDynamicalSystems.log_likelihood_function, models/LinearDynamicalSystems.py:244-266: invSigmamu_t and Residual of
  * every (time, series) from ONE read of the observations).  P dense (k,k); b (k) or NULL; c0 one element in device memory or

@@ -15,8 +15,9 @@ LIB_PATH = os.path.join(_HERE, "libvbmp_hip.so")
 _c_i64 = ctypes.c_int64
 _c_int = ctypes.c_int
 _c_ptr = ctypes.c_void_p
+_c_double = ctypes.c_double
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _lib = None
 
@@ -147,6 +148,16 @@ SYMBOLS = {
     "vbmp_niw_estep_params": lambda T: [_c_ptr] * 6 + [_c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
     # mu, U, nu, V, logdet_invU, NB, n, p, R, G, H, El, stream
     "vbmp_mnw_expectations": lambda T: [_c_ptr] * 5 + [_c_i64, _c_int, _c_int] + [_c_ptr] * 5,
+    # K15: alpha, alpha0, s0, NB, K, out, stream
+    "vbmp_dirichlet_kl": lambda T: [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_ptr],
+    # alpha, beta, alpha0, beta0, sa0, sb0, NB, K, out, stream
+    "vbmp_gamma_kl": lambda T: [_c_ptr] * 4 + [_c_i64, _c_i64, _c_i64, _c_int, _c_ptr],
+    # invU0, sm0, U, nu, nu0, sn0, ld, ld0, sl0, mu, mu0, smu0, lam, lam0, slam0, NB, n, out, stream
+    "vbmp_wishart_kl": lambda T: [_c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_i64,
+                                  _c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_ptr],
+    # mu, mu0, smu0, invV0, sv0, V, R, ldV, ldV0, sl0, xm, NB, n, p, out, stream
+    "vbmp_mn_kl": lambda T: [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_double, _c_i64,
+                             _c_int, _c_int, _c_ptr],
     # X, S, k, M, c, n, out, P, b, c0, q, stream
     "vbmp_rows_affine_quad": lambda T: [_c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
 }

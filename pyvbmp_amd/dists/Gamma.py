@@ -81,6 +81,12 @@ class Gamma():
         return _FORMULAS["logZ"](self.alpha_0, self.beta_0)
 
     def KLqprior(self):
+        if self.alpha.is_cuda:  # K15: one launch
+            from .. import ops
+            return ops.gamma_kl(self.alpha, self.beta, self.alpha_0, self.beta_0, self.event_dim)
+        return self._KLqprior_composed()
+
+    def _KLqprior_composed(self):
         a, b, a0, b0 = self.alpha, self.beta, self.alpha_0, self.beta_0
         kl = (a - a0) * torch.digamma(a) - torch.lgamma(a) + torch.lgamma(a0) + a0 * (torch.log(b) - torch.log(b0)) \
             + a * (b0 / b - 1)

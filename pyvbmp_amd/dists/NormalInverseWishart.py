@@ -147,6 +147,17 @@ class NormalInverseWishart():
         return W.EinvSigma(), self.EinvSigmamu(), c
 
     def KLqprior(self):
+        W = self.invU
+        if self.mu.is_cuda and type(W) is Wishart:  # K15: Wishart and Normal part in one launch
+            lead = tuple(self.mu.shape[:-1])
+            kl = ops.wishart_kl(W.invU_0, W.U, W.nu, W.nu_0, W.logdet_invU, W.logdet_invU_0, mu=self.mu, mu0=self.mu_0,
+                                lam=self.lambda_mu.expand(lead), lam0=self.lambda_mu_0.expand(lead))
+            for i in range(self.event_dim - 1):
+                kl = kl.sum(-1)
+            return kl
+        return self._KLqprior_composed()
+
+    def _KLqprior_composed(self):
         d = self.mu - self.mu_0
         Pd = (self.invU.mean() * d.unsqueeze(-2)).sum(-1)
         KL = 0.5 * (self.lambda_mu_0 / self.lambda_mu - 1 + (self.lambda_mu / self.lambda_mu_0).log()) * self.dim

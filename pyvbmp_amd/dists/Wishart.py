@@ -85,6 +85,14 @@ class Wishart():
         return torch.log(self.nu) - self.logdet_invU
 
     def KLqprior(self):
+        if self.U.is_cuda:  # K15: one launch
+            kl = ops.wishart_kl(self.invU_0, self.U, self.nu, self.nu_0, self.logdet_invU, self.logdet_invU_0)
+            for _ in range(self.event_dim - 2):
+                kl = kl.sum(-1)
+            return kl
+        return self._KLqprior_composed()
+
+    def _KLqprior_composed(self):
         half, half0 = 0.5 * self.nu, 0.5 * self.nu_0
         trace_term = (self.invU_0 * self.U).sum((-1, -2))  # tr(invU_0 U)
         kl = half0 * (self.logdet_invU - self.logdet_invU_0) + half * (trace_term - self.dim)

@@ -639,6 +639,103 @@ def niw_estep_params(U, nu, mu, lam, logdet_invU, alpha=None):
     return P, b, c
 
 
+def _prior_operand(t, lead, tail, dt):
+    """(tensor, batch stride in elements) of a prior operand of shape lead + tail for the K15 kernels: stride 0 when it is ONE
+    element expanded over the batch (the reference's expanded priors), prod(tail) when dense; anything else is made dense"""
+    t = t.to(dt) if t.dtype != dt else t
+    t = t.expand(tuple(lead) + tuple(tail))
+    nl = len(lead)
+    inner = t
+    if nl and all(st == 0 or sz == 1 for st, sz in zip(t.stride()[:nl], t.shape[:nl])):
+        inner = t[(0,) * nl]
+        if inner.is_contiguous():
+            return inner, 0
+    if t.is_contiguous():
+        return t, _prod(tail)
+    return t.contiguous(), _prod(tail)
+
+
+def _dense(t, shape, dt):
+    t = t.to(dt) if t.dtype != dt else t
+    return t.expand(tuple(shape)).contiguous()
+
+
+def dirichlet_kl(alpha, alpha0, event_dim):
+    """K15: Dirichlet.KLqprior per batch element (the trailing event_dim axes are one event)"""
+    dev = L.require_device(alpha, alpha0)
+    lib, dt = L.load(), alpha.dtype
+    lead, ev = tuple(alpha.shape[:alpha.ndim - event_dim]), tuple(alpha.shape[alpha.ndim - event_dim:])
+    NB, K = _prod(lead), _prod(ev)
+    a = _dense(alpha, lead + ev, dt)
+    a0, s0 = _prior_operand(alpha0, lead, ev, dt)
+    out = torch.empty(lead, dtype=dt, device=dev)
+    if NB > 0:
+        L.call(getattr(lib, "vbmp_dirichlet_kl_" + L.suffix(dt)), "vbmp_dirichlet_kl", L.ptr(a), L.ptr(a0), s0, NB, K, L.ptr(out),
+               L.stream_ptr(dev))
+    return out
+
+
+def gamma_kl(alpha, beta, alpha0, beta0, event_dim):
+    """K15: Gamma.KLqprior summed over the trailing event_dim axes"""
+    dev = L.require_device(alpha, beta, alpha0, beta0)
+    lib, dt = L.load(), alpha.dtype
+    lead, ev = tuple(alpha.shape[:alpha.ndim - event_dim]), tuple(alpha.shape[alpha.ndim - event_dim:])
+    NB, K = _prod(lead), _prod(ev)
+    a, b = _dense(alpha, lead + ev, dt), _dense(beta, lead + ev, dt)
+    a0, sa0 = _prior_operand(alpha0, lead, ev, dt)
+    b0, sb0 = _prior_operand(beta0, lead, ev, dt)
+    out = torch.empty(lead, dtype=dt, device=dev)
+    if NB > 0:
+        L.call(getattr(lib, "vbmp_gamma_kl_" + L.suffix(dt)), "vbmp_gamma_kl", L.ptr(a), L.ptr(b), L.ptr(a0), L.ptr(b0), sa0, sb0, NB,
+               K, L.ptr(out), L.stream_ptr(dev))
+    return out
+
+
+def wishart_kl(invU0, U, nu, nu0, ld, ld0, mu=None, mu0=None, lam=None, lam0=None):
+    """K15: Wishart.KLqprior per n x n element (lead = U.shape[:-2]); with mu .. lam0 also the Normal part of
+    NormalInverseWishart.KLqprior (mu, mu0: lead + (n,), lam, lam0: lead)"""
+    dev = L.require_device(invU0, U, nu, nu0, ld, ld0, mu, mu0, lam, lam0)
+    lib, dt = L.load(), U.dtype
+    lead, n = tuple(U.shape[:-2]), U.shape[-1]
+    NB = _prod(lead)
+    Ud, nud, ldd = _dense(U, lead + (n, n), dt), _dense(nu, lead, dt), _dense(ld, lead, dt)
+    I0, sm0 = _prior_operand(invU0, lead, (n, n), dt)
+    n0, sn0 = _prior_operand(nu0, lead, (), dt)
+    l0, sl0 = _prior_operand(ld0, lead, (), dt)
+    if mu is not None:
+        mud, lamd = _dense(mu, lead + (n,), dt), _dense(lam, lead, dt)
+        m0, smu0 = _prior_operand(mu0, lead, (n,), dt)
+        la0, slam0 = _prior_operand(lam0, lead, (), dt)
+        extra = (L.ptr(mud), L.ptr(m0), smu0, L.ptr(lamd), L.ptr(la0), slam0)
+    else:
+        extra = (None, None, 0, None, None, 0)
+    out = torch.empty(lead, dtype=dt, device=dev)
+    if NB > 0:
+        L.call(getattr(lib, "vbmp_wishart_kl_" + L.suffix(dt)), "vbmp_wishart_kl", L.ptr(I0), sm0, L.ptr(Ud), L.ptr(nud), L.ptr(n0),
+               sn0, L.ptr(ldd), L.ptr(l0), sl0, *extra, NB, n, L.ptr(out), L.stream_ptr(dev))
+    return out
+
+
+MN_KL_MAX_NP = 8192
+
+
+def mn_kl(mu, mu0, invV0, V, R, ldV, ldV0, xm=0.0):
+    """K15: the matrix-normal part of MatrixNormalWishart / MatrixNormalGamma.KLqprior; mu: lead + (n, p), R: lead + (n, n)"""
+    dev = L.require_device(mu, mu0, invV0, V, R, ldV, ldV0)
+    lib, dt = L.load(), mu.dtype
+    lead, (n, p) = tuple(mu.shape[:-2]), mu.shape[-2:]
+    NB = _prod(lead)
+    mud, Vd, Rd, ldd = _dense(mu, lead + (n, p), dt), _dense(V, lead + (p, p), dt), _dense(R, lead + (n, n), dt), _dense(ldV, lead, dt)
+    m0, smu0 = _prior_operand(mu0, lead, (n, p), dt)
+    I0, sv0 = _prior_operand(invV0, lead, (p, p), dt)
+    l0, sl0 = _prior_operand(ldV0, lead, (), dt)
+    out = torch.empty(lead, dtype=dt, device=dev)
+    if NB > 0:
+        L.call(getattr(lib, "vbmp_mn_kl_" + L.suffix(dt)), "vbmp_mn_kl", L.ptr(mud), L.ptr(m0), smu0, L.ptr(I0), sv0, L.ptr(Vd),
+               L.ptr(Rd), L.ptr(ldd), L.ptr(l0), sl0, float(xm), NB, n, p, L.ptr(out), L.stream_ptr(dev))
+    return out
+
+
 def mnw_expectations(mu, U, nu, V, logdet_invU):
     """K14: (EinvSigma, EinvUX, EXTinvUX, ElogdetinvSigma) of a MatrixNormalWishart posterior, one launch.  mu: lead + (n, p),
     U: lead + (n, n), nu / logdet_invU: lead, V: lead + (p, p) (operands may be broadcast over lead)."""

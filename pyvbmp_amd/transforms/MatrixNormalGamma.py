@@ -52,6 +52,15 @@ class MatrixNormalGamma(MatrixNormalWishart):
         return (ops.spd_inverse(Kp) @ rhs.unsqueeze(-1)).squeeze(-1)
 
     def KLqprior(self):
+        KL = self._mn_kl()  # (K15; R = the diagonal E[invSigma] of this class)
+        if KL is None:
+            return self._KLqprior_composed()
+        KL = KL + (self.invU.KLqprior() / self.n if self.uniform_precision is True else self.invU.KLqprior())
+        for i in range(self.event_dim - 2):
+            KL = KL.sum(-1)
+        return KL
+
+    def _KLqprior_composed(self):
         KL = self.n / 2.0 * self.logdetinvV - self.n / 2.0 * self.logdetinvV_0 - self.n * self.p / 2.0
         if self.X_mask is not None:
             KL = KL + self.n / 2.0 * self.logdetinvV_0 * (self.X_mask).sum((-1, -2))

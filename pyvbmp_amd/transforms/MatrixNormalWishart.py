@@ -276,7 +276,33 @@ class MatrixNormalWishart():
         SExx, SEyx, SEyy, N = self._moments(X, Y, None, None, p)
         self.ss_update(SExx, SEyx, SEyy, N, lr=lr, beta=beta)
 
+    def _mn_kl(self):
+        """the matrix-normal part of KLqprior from one launch (K15), or None where the kernel does not serve (state off the GPU,
+        n p beyond its LDS image, an X_mask that differs over the batch)"""
+        if not self.mu.is_cuda or self.n * self.p > ops.MN_KL_MAX_NP:
+            return None
+        xm = 0.0
+        if self.X_mask is not None:
+            if self.X_mask.ndim > 2:
+                return None
+            xm = self.__dict__.get("_xmask_count")
+            if xm is None:  # the mask never changes: counted once (one host synchronisation, at the first evidence evaluation)
+                xm = self._xmask_count = float(self.X_mask.sum())
+        lead = tuple(self.mu.shape[:-2])
+        R = self.EinvSigma()
+        KL = ops.mn_kl(self.mu, self.mu_0, self.invV_0, self.V, R.expand(lead + tuple(R.shape[-2:])), self.logdetinvV,
+                       self.logdetinvV_0, xm)
+        for i in range(self.event_dim - 2):
+            KL = KL.sum(-1)
+        return KL
+
     def KLqprior(self):
+        KL = self._mn_kl()
+        if KL is not None:
+            return KL + self.invU.KLqprior()
+        return self._KLqprior_composed()
+
+    def _KLqprior_composed(self):
         KL = self.n / 2.0 * self.logdetinvV - self.n / 2.0 * self.logdetinvV_0 - self.n * self.p / 2.0
         if self.X_mask is not None:
             KL = KL + self.n / 2.0 * self.logdetinvV_0 * (self.X_mask).sum((-1, -2))
