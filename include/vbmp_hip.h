@@ -327,7 +327,7 @@ int vbmp_mnw_expectations_f32(const float* mu, const float* U, const float* nu, 
  *                  NormalInverseWishart.KLqprior (dists/NormalInverseWishart.py:134-141): mu / mu0 (NB, n), lam / lam0 (NB).
  *   mn_kl        : the matrix-normal part of MatrixNormalWishart / MatrixNormalGamma.KLqprior (transforms/MatrixNormalWishart.py:
  *                  206-215, MatrixNormalGamma.py:203-214) for an (n x p) transform: R = E[invSigma] (NB, n, n), xm = number of set
- *                  entries of X_mask (0 without one); n p <= 8192. */
+ *                  entries of X_mask per batch element (a prior-like operand with its stride; NULL without a mask); n p + p max(n, p) <= 8192. */
 int vbmp_dirichlet_kl_f64(const double* alpha, const double* alpha0, int64_t s0, int64_t NB, int K, double* out, void* stream);
 int vbmp_dirichlet_kl_f32(const float* alpha, const float* alpha0, int64_t s0, int64_t NB, int K, float* out, void* stream);
 int vbmp_gamma_kl_f64(const double* alpha, const double* beta, const double* alpha0, const double* beta0, int64_t sa0, int64_t sb0,
@@ -341,10 +341,11 @@ int vbmp_wishart_kl_f32(const float* invU0, int64_t sm0, const float* U, const f
                         const float* ld, const float* ld0, int64_t sl0, const float* mu, const float* mu0, int64_t smu0,
                         const float* lam, const float* lam0, int64_t slam0, int64_t NB, int n, float* out, void* stream);
 int vbmp_mn_kl_f64(const double* mu, const double* mu0, int64_t smu0, const double* invV0, int64_t sv0, const double* V,
-                   const double* R, const double* ldV, const double* ldV0, int64_t sl0, double xm, int64_t NB, int n, int p,
-                   double* out, void* stream);
+                   const double* R, const double* ldV, const double* ldV0, int64_t sl0, const double* xm, int64_t sxm, int64_t NB,
+                   int n, int p, double* out, void* stream);
 int vbmp_mn_kl_f32(const float* mu, const float* mu0, int64_t smu0, const float* invV0, int64_t sv0, const float* V, const float* R,
-                   const float* ldV, const float* ldV0, int64_t sl0, double xm, int64_t NB, int n, int p, float* out, void* stream);
+                   const float* ldV, const float* ldV0, int64_t sl0, const float* xm, int64_t sxm, int64_t NB, int n, int p, float* out,
+                   void* stream);
 /* K12 with the observation likelihood's scalar in the same pass: additionally q[s] = -1/2 x' P x + b' x + c0[0]
  * (LinearDynamicalSystems.log_likelihood_function, models/LinearDynamicalSystems.py:244-266: invSigmamu_t and Residual of
  * every (time, series) from ONE read of the observations).  P dense (k,k); b (k) or NULL; c0 one element in device memory or

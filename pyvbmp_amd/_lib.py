@@ -155,8 +155,8 @@ SYMBOLS = {
     # invU0, sm0, U, nu, nu0, sn0, ld, ld0, sl0, mu, mu0, smu0, lam, lam0, slam0, NB, n, out, stream
     "vbmp_wishart_kl": lambda T: [_c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_i64,
                                   _c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_ptr],
-    # mu, mu0, smu0, invV0, sv0, V, R, ldV, ldV0, sl0, xm, NB, n, p, out, stream
-    "vbmp_mn_kl": lambda T: [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_double, _c_i64,
+    # mu, mu0, smu0, invV0, sv0, V, R, ldV, ldV0, sl0, xm, sxm, NB, n, p, out, stream
+    "vbmp_mn_kl": lambda T: [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64,
                              _c_int, _c_int, _c_ptr],
     # X, S, k, M, c, n, out, P, b, c0, q, stream
     "vbmp_rows_affine_quad": lambda T: [_c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr],

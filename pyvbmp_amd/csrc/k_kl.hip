@@ -116,14 +116,15 @@ __global__ __launch_bounds__(64) void k_wishart_kl(const T* __restrict__ invU0, 
 
 // the matrix-normal part of MatrixNormalWishart / MatrixNormalGamma.KLqprior for an (n x p) transform:
 //   n/2 (ldV - ldV0) - n p / 2 [+ n/2 ldV0 xm] + n/2 tr(invV0 V) + 1/2 tr(invV0 d' R d),   d = mu - mu0, R = E[invSigma] (n x n)
-// (xm: the number of set entries of X_mask, 0 without one).  LDS: E = d invV0 (n x p).
+// (xm: the number of set entries of X_mask per batch element, NULL without one).  LDS: E = d invV0 (n x p).
 template <typename T>
 __global__ __launch_bounds__(1024) void k_mn_kl(const T* __restrict__ mu, const T* __restrict__ mu0, int64_t smu0,
-                                               const T* __restrict__ invV0, int64_t sv0, const T* __restrict__ V,
-                                               const T* __restrict__ R, const T* __restrict__ ldV, const T* __restrict__ ldV0,
-                                               int64_t sl0, double xm, int n, int p, T* __restrict__ out) {
+                                                const T* __restrict__ invV0, int64_t sv0, const T* __restrict__ V,
+                                                const T* __restrict__ R, const T* __restrict__ ldV, const T* __restrict__ ldV0,
+                                                int64_t sl0, const T* __restrict__ xm, int64_t sxm, int n, int p, T* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kl_smem[];
-  double* E = reinterpret_cast<double*>(kl_smem);  // n x p
+  double* Dm = reinterpret_cast<double*>(kl_smem);  // d = mu - mu0 (n x p)
+  double* Bm = Dm + n * p;                          // invV0 (p x p), then E = d invV0 (n x p)
   __shared__ double red[16];
   const int64_t b = blockIdx.x;
   const int tid = threadIdx.x;
@@ -132,23 +133,39 @@ __global__ __launch_bounds__(1024) void k_mn_kl(const T* __restrict__ mu, const 
   const T* I0 = invV0 + b * sv0;
   const T* Vb = V + b * (int64_t)p * p;
   const T* Rb = R + b * (int64_t)n * n;
-  for (int e = tid; e < n * p; e += 1024) {
-    const int i = e / p, c = e - i * p;
-    double acc = 0;
-#pragma unroll 8
-    for (int a = 0; a < p; ++a) acc += ((double)m[i * p + a] - (double)m0[i * p + a]) * (double)I0[a * p + c];  // (loads of 8 terms in flight)
-    E[e] = acc;
+  double part = 0;
+  for (int e = tid; e < n * p; e += 1024) Dm[e] = (double)m[e] - (double)m0[e];
+  for (int e = tid; e < p * p; e += 1024) {
+    const double i0 = (double)I0[e];
+    Bm[e] = i0;
+    part += 0.5 * n * i0 * (double)Vb[e];
   }
   __syncthreads();
-  double part = 0;
+  constexpr int NE = 8;  // n p <= 8192: at most 8 entries of E per thread
+  double ev[NE];
+#pragma unroll
+  for (int u = 0; u < NE; ++u) {
+    const int e = tid + 1024 * u;
+    double acc = 0;
+    if (e < n * p) {
+      const int i = e / p, c = e - i * p;
+      for (int a = 0; a < p; ++a) acc += Dm[i * p + a] * Bm[a * p + c];
+    }
+    ev[u] = acc;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < NE; ++u) {
+    const int e = tid + 1024 * u;
+    if (e < n * p) Bm[e] = ev[u];
+  }
+  __syncthreads();
   for (int e = tid; e < n * n; e += 1024) {  // sum_{i,k} R[i][k] (E d')[i][k]
     const int i = e / n, k = e - i * n;
     double acc = 0;
-#pragma unroll 8
-    for (int c = 0; c < p; ++c) acc += E[i * p + c] * ((double)m[k * p + c] - (double)m0[k * p + c]);
+    for (int c = 0; c < p; ++c) acc += Bm[i * p + c] * Dm[k * p + c];
     part += 0.5 * (double)Rb[e] * acc;
   }
-  for (int e = tid; e < p * p; e += 1024) part += 0.5 * n * (double)I0[e] * (double)Vb[e];
   part = kl_wave_sum(part);
   if ((tid & 63) == 0) red[tid >> 6] = part;
   __syncthreads();
@@ -156,7 +173,7 @@ __global__ __launch_bounds__(1024) void k_mn_kl(const T* __restrict__ mu, const 
     const double l0 = (double)ldV0[b * sl0];
     double tot = 0;
     for (int w = 0; w < 16; ++w) tot += red[w];
-    out[b] = (T)(tot + 0.5 * n * ((double)ldV[b] - l0) - 0.5 * n * p + 0.5 * n * l0 * xm);
+    out[b] = (T)(tot + 0.5 * n * ((double)ldV[b] - l0) - 0.5 * n * p + 0.5 * n * l0 * (xm ? (double)xm[b * sxm] : 0.0));
   }
 }
 
@@ -192,15 +209,15 @@ using namespace vbmp;
     return launch_ok<T>();                                                                                                          \
   }                                                                                                                                 \
   extern "C" int vbmp_mn_kl_##SUF(const T* mu, const T* mu0, int64_t smu0, const T* invV0, int64_t sv0, const T* V, const T* R,     \
-                                  const T* ldV, const T* ldV0, int64_t sl0, double xm, int64_t NB, int n, int p, T* out,            \
-                                  void* stream) {                                                                                   \
+                                  const T* ldV, const T* ldV0, int64_t sl0, const T* xm, int64_t sxm, int64_t NB, int n, int p,   \
+                                  T* out, void* stream) {                                                                                   \
     if (NB == 0) return 0;                                                                                                          \
     if (!mu || !mu0 || !invV0 || !V || !R || !ldV || !ldV0 || !out || NB < 0 || NB > 0x7fffffff || n < 1 || p < 1)                 \
       return VBMP_ERR_ARG;                                                                                                          \
-    const size_t smem = (size_t)n * p * sizeof(double);                                                                             \
-    if (smem > 64 * 1024) return VBMP_ERR_ARG; /* n p <= 8192: beyond it the caller composes the term */                          \
+    const size_t smem = ((size_t)n * p + (size_t)p * (n > p ? n : p)) * sizeof(double);                                             \
+    if (smem > 64 * 1024 || (size_t)n * p > 8192) return VBMP_ERR_ARG; /* beyond it the caller composes the term */                \
     hipLaunchKernelGGL((k_mn_kl<T>), dim3((unsigned)NB), dim3(1024), smem, (hipStream_t)stream, mu, mu0, smu0, invV0, sv0, V, R,     \
-                       ldV, ldV0, sl0, xm, n, p, out);                                                                              \
+                       ldV, ldV0, sl0, xm, sxm, n, p, out);                                                                              \
     return launch_ok<T>();                                                                                                          \
   }
 VBMP_KL_ENTRIES(double, f64)

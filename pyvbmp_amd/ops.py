@@ -716,10 +716,14 @@ def wishart_kl(invU0, U, nu, nu0, ld, ld0, mu=None, mu0=None, lam=None, lam0=Non
     return out
 
 
-MN_KL_MAX_NP = 8192
+MN_KL_MAX_LDS = 8192  # doubles of LDS the matrix-normal KL kernel stages its operands in: n p + p max(n, p)
 
 
-def mn_kl(mu, mu0, invV0, V, R, ldV, ldV0, xm=0.0):
+def mn_kl_serves(n, p):
+    return n * p + p * max(n, p) <= MN_KL_MAX_LDS
+
+
+def mn_kl(mu, mu0, invV0, V, R, ldV, ldV0, xm=None):
     """K15: the matrix-normal part of MatrixNormalWishart / MatrixNormalGamma.KLqprior; mu: lead + (n, p), R: lead + (n, n)"""
     dev = L.require_device(mu, mu0, invV0, V, R, ldV, ldV0)
     lib, dt = L.load(), mu.dtype
@@ -729,10 +733,11 @@ def mn_kl(mu, mu0, invV0, V, R, ldV, ldV0, xm=0.0):
     m0, smu0 = _prior_operand(mu0, lead, (n, p), dt)
     I0, sv0 = _prior_operand(invV0, lead, (p, p), dt)
     l0, sl0 = _prior_operand(ldV0, lead, (), dt)
+    xmo, sxm = (None, 0) if xm is None else _prior_operand(xm, lead, (), dt)  # set entries of X_mask per batch element
     out = torch.empty(lead, dtype=dt, device=dev)
     if NB > 0:
         L.call(getattr(lib, "vbmp_mn_kl_" + L.suffix(dt)), "vbmp_mn_kl", L.ptr(mud), L.ptr(m0), smu0, L.ptr(I0), sv0, L.ptr(Vd),
-               L.ptr(Rd), L.ptr(ldd), L.ptr(l0), sl0, float(xm), NB, n, p, L.ptr(out), L.stream_ptr(dev))
+               L.ptr(Rd), L.ptr(ldd), L.ptr(l0), sl0, L.ptr(xmo), sxm, NB, n, p, L.ptr(out), L.stream_ptr(dev))
     return out
 
 

@@ -278,16 +278,14 @@ class MatrixNormalWishart():
 
     def _mn_kl(self):
         """the matrix-normal part of KLqprior from one launch (K15), or None where the kernel does not serve (state off the GPU,
-        n p beyond its LDS image, an X_mask that differs over the batch)"""
-        if not self.mu.is_cuda or self.n * self.p > ops.MN_KL_MAX_NP:
+        n p beyond its LDS image)"""
+        if not self.mu.is_cuda or not ops.mn_kl_serves(self.n, self.p):
             return None
-        xm = 0.0
+        xm = None
         if self.X_mask is not None:
-            if self.X_mask.ndim > 2:
-                return None
-            xm = self.__dict__.get("_xmask_count")
-            if xm is None:  # the mask never changes: counted once (one host synchronisation, at the first evidence evaluation)
-                xm = self._xmask_count = float(self.X_mask.sum())
+            xm = self.__dict__.get("_vbmp_xmask_count")
+            if xm is None:  # the mask never changes: its set entries are counted once (per batch element)
+                xm = self._vbmp_xmask_count = self.X_mask.sum((-1, -2)).to(self.dtype)
         lead = tuple(self.mu.shape[:-2])
         R = self.EinvSigma()
         KL = ops.mn_kl(self.mu, self.mu_0, self.invV_0, self.V, R.expand(lead + tuple(R.shape[-2:])), self.logdetinvV,

@@ -82,7 +82,8 @@ def test_niw_kl(event, batch, dtype, tol):
 @pytest.mark.parametrize("dtype, tol", DT)
 @pytest.mark.parametrize("cls", ["wishart", "gamma"])
 @pytest.mark.parametrize("event, batch, pad, xmask", [((3, 2), (), False, False), ((4, 5), (6,), True, False),
-                                                      ((4, 52), (25,), True, True), ((2, 3, 4), (5,), False, False)])
+                                                      ((4, 52), (25,), True, True), ((3, 6), (4,), False, True), ((2, 3, 4), (5,), False, False),
+                                                      ((52, 52), (), True, False), ((64, 64), (2,), False, False)])
 def test_matrix_normal_kl(event, batch, pad, xmask, cls, dtype, tol):
     from pyvbmp_amd.transforms.MatrixNormalGamma import MatrixNormalGamma
     from pyvbmp_amd.transforms.MatrixNormalWishart import MatrixNormalWishart
@@ -90,8 +91,8 @@ def test_matrix_normal_kl(event, batch, pad, xmask, cls, dtype, tol):
     C = MatrixNormalWishart if cls == "wishart" else MatrixNormalGamma
     n, px = event[-2], event[-1]
     X_mask = None
-    if xmask:
-        X_mask = (torch.rand(1, px, device="cuda") > 0.3)
+    if xmask:  # one mask per batch element, as DynamicMarkovBlanketDiscovery builds for its emission model
+        X_mask = (torch.rand(batch + (1, px), device="cuda") > 0.3)
     m = C(event, batch, pad_X=pad, X_mask=X_mask, device="cuda", dtype=dtype)
     lead = batch + tuple(event[:-2])
     X = torch.randn((80,) + (1,) * len(lead) + (px, 1), device="cuda", dtype=dtype)
