@@ -16,7 +16,7 @@ import math
 import torch
 
 from .. import ops
-from .._common import resolve, shared_matvec
+from .._common import derived_key, resolve, shared_matvec
 from ..dists.MultivariateNormal_vector_format import MultivariateNormal_vector_format
 from ..dists.NormalInverseWishart import NormalInverseWishart
 from ..transforms.MatrixNormalGamma import MatrixNormalGamma
@@ -299,7 +299,7 @@ class LinearDynamicalSystems():
         self.invQ = self.A.EinvSigma()
         ATQA = self.A.EXTinvUX()
         self.ATQA_x_x = ATQA[..., :h, :h].contiguous()  # (dense once here: the smoother launch of every E-step wants it dense)
-        self.invATQA_x_x, self.logdetATQA_x_x = ops.spd_inv_logdet(self.ATQA_x_x)
+        self._vbmp_invATQA = None  # invATQA_x_x / logdetATQA_x_x (reference attributes; the device smoother never reads them): on demand
         self.ATQA_x_u = ATQA[..., :h, h:]
         self.ATQA_u_u = ATQA[..., h:, h:]
         QA = self.A.EinvUX()
@@ -307,6 +307,21 @@ class LinearDynamicalSystems():
         self.QA_xp_u = QA[..., :, h:]
         # E log|invQ|: a function of the transition's noise parameters like the blocks above (six launches per E-step otherwise)
         self.A_Elogdet = self.A.ElogdetinvSigma()
+
+    def _inv_ATQA(self):
+        key = derived_key(self.ATQA_x_x)  # (identity, version, graph-replay epoch)
+        c = self.__dict__.get("_vbmp_invATQA")
+        if c is None or c[0] != key:
+            c = self._vbmp_invATQA = (key,) + tuple(ops.spd_inv_logdet(self.ATQA_x_x)) + (self.ATQA_x_x,)
+        return c
+
+    @property
+    def invATQA_x_x(self):
+        return self._inv_ATQA()[1]
+
+    @property
+    def logdetATQA_x_x(self):
+        return self._inv_ATQA()[2]
 
     def log_likelihood_function(self, Y, R):
         """natural parameters of the likelihood of x_t (ref :244-266)"""
