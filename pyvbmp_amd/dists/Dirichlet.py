@@ -7,7 +7,7 @@ samples) come out of the fused E-step kernels.
 """
 import torch
 
-from .._common import as_param, resolve
+from .._common import as_param, blend, derived_key, resolve
 
 
 def _finite(values, bad):
@@ -44,7 +44,7 @@ class Dirichlet():
     def ss_update(self, NA, lr=1.0, beta=None):
         assert NA.shape == self.batch_shape + self.event_shape
         self.NA = NA if beta is None else beta * self.NA + NA
-        self.alpha = lr * (self.alpha_0 + self.NA) + (1 - lr) * self.alpha
+        self.alpha = blend(self.alpha_0 + self.NA, self.alpha, lr)
 
     def raw_update(self, X, p=None, lr=1.0, beta=None):
         sample_axes = tuple(range(X.ndim - self.event_dim - self.batch_dim))
@@ -61,7 +61,12 @@ class Dirichlet():
         return self.alpha / self._total()
 
     def loggeomean(self):
-        return torch.digamma(self.alpha) - torch.digamma(self._total())
+        # kept until alpha is rebound or written: a VB iteration reads it in the E-step and again in the evidence (4 launches each)
+        key = derived_key(self.alpha)
+        c = self.__dict__.get("_vbmp_loggeomean")
+        if c is None or c[0] != key:
+            c = self._vbmp_loggeomean = (key, torch.digamma(self.alpha) - torch.digamma(self._total()), self.alpha)
+        return c[1]
 
     ElogX = loggeomean
 

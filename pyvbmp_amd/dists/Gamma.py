@@ -7,7 +7,7 @@ one table (name -> formula) from which the reference's getter methods are genera
 """
 import torch
 
-from .._common import as_param, resolve
+from .._common import as_param, blend, resolve
 
 # closed forms of Gamma(shape a, rate b)
 _FORMULAS = {
@@ -52,8 +52,8 @@ class Gamma():
         if beta is not None:
             self.SEx, self.SElogx = beta * self.SEx + SEx, beta * self.SElogx + SElogx
             SEx, SElogx = self.SEx, self.SElogx
-        self.alpha = lr * (self.alpha_0 + SElogx) + (1 - lr) * self.alpha
-        self.beta = lr * (self.beta_0 + SEx) + (1 - lr) * self.beta
+        self.alpha = blend(self.alpha_0 + SElogx, self.alpha, lr)
+        self.beta = blend(self.beta_0 + SEx, self.beta, lr)
 
     def _count_and_sum(self, X, p):
         """(sum_s p_s x_s, sum_s p_s) over the sample axes; p None = unit weights"""

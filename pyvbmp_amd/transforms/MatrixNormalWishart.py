@@ -16,7 +16,7 @@ import math
 import torch
 
 from .. import ops
-from .._common import as_param, derived_key, resolve, shared_matvec
+from .._common import as_param, blend, derived_key, resolve, shared_matvec
 from ..dists.MultivariateNormal_vector_format import MultivariateNormal_vector_format
 from ..dists.Wishart import Wishart
 from ..utils.matrix_utils import matrix_utils
@@ -147,9 +147,9 @@ class MatrixNormalWishart():
         if self.fixed_precision is False:
             W_arg = SEyy - mu @ invV @ _T(mu) + self.mu_0 @ self.invV_0 @ _T(self.mu_0)
             self._update_noise(W_arg, N, lr)
-        invV = lr * invV + (1.0 - lr) * self.invV
+        invV = blend(invV, self.invV, lr)
         self.invV = 0.5 * (invV + _T(invV))
-        self.mu = lr * mu + (1.0 - lr) * self.mu
+        self.mu = blend(mu, self.mu, lr)
         if self.mask is not None:
             self.mu = self.mu * self.mask
         self.V, self.logdetinvV = ops.spd_inv_logdet(self.invV)
