@@ -398,8 +398,11 @@ class DmbdWorkload:
         return cfg
 
     def roofline_extra(self):
-        return {"bytes_per_t_series": self.bpu, "note": "the smoother (h = 52, block-per-series form) is latency / issue bound, "
-                "not HBM-bound: the fraction is reported for completeness"}
+        return {"bytes_per_t_series": self.bpu,
+                "kernel_ms_covers": "the ONE vbmp_lds_smoother call of an iteration = its four launches: k_lds_smoother_blk (the two "
+                                    "recursions) + k_lds_blk_cross + k_lds_blk_post + k_lds_blk_sums; their rocprofv3 averages add up to it",
+                "note": "the smoother (h = 52, block-per-series form) is latency / issue bound, not HBM-bound: the fraction is "
+                        "reported for completeness"}
 
     def traffic_key(self):
         return f"dmbd_{self.dtype_name}_T{self.T}_S{self.S}"
