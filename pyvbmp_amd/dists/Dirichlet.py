@@ -62,7 +62,7 @@ class Dirichlet():
 
     def loggeomean(self):
         # kept until alpha is rebound or written: a VB iteration reads it in the E-step and again in the evidence (4 launches each)
-        key = derived_key(self.alpha)
+        key = derived_key(self.alpha) + (self.event_dim,)
         c = self.__dict__.get("_vbmp_loggeomean")
         if c is None or c[0] != key:
             c = self._vbmp_loggeomean = (key, torch.digamma(self.alpha) - torch.digamma(self._total()), self.alpha)
