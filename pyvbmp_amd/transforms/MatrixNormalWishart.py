@@ -354,16 +354,37 @@ class MatrixNormalWishart():
                 # compact covariances and expanded, instead of materialising the view for the GEMM
                 idx = tuple(slice(0, 1) if (C.stride(i) == 0 and C.shape[i] > 1) else slice(None) for i in range(ns))
                 Cc = C[idx]
-                out = Cc.reshape(-1, d * d) @ Pb.reshape(-1, d * d).transpose(0, 1)
+                Cf, Pf = Cc.reshape(-1, d * d), Pb.reshape(-1, d * d)
+                keep = self._xmask_union(d) if Pb is Px else None
+                if keep is not None:  # entries that X_mask zeroes in EVERY expert's precision drop out of the inner dimension
+                    Cf, Pf = Cf.index_select(1, keep), Pf.index_select(1, keep)
+                out = Cf @ Pf.transpose(0, 1)
                 return out.reshape(tuple(Cc.shape[:ns]) + tuple(Pb.shape[:-2])).expand(lead_s + tuple(Pb.shape[:-2]))
             return (C * Pb).sum((-1, -2))
+        Px = P[..., :px, :px]
         if cx is not None:
-            ELL = ELL - 0.5 * trace_term(cx, P[..., :px, :px])
+            ELL = ELL - 0.5 * trace_term(cx, Px)
         if cy is not None:
             ELL = ELL - 0.5 * trace_term(cy, P[..., px:, px:])
         for i in range(self.event_dim - 2):
             ELL = ELL.sum(-1)
         return ELL
+
+    def _xmask_union(self, px):
+        """flat indices of the (px x px) entries of E[X' invU X] that X_mask leaves free in at least one batch element, or None when
+        there is no mask / the union covers more than half of the matrix.  E[X' invU X] = n V + mu' R mu is EXACTLY zero outside
+        X_mask (x) X_mask (V and mu are masked), so a trace against it only needs those entries: for the 25 roles of the flocking
+        DMBD, each reading one object's 8 latent dimensions, 400 of 2 704 -- the trace-term GEMM of the role assignments was 0.15 ms,
+        a fifth of the E-step.  The mask never changes: found once (one host synchronisation)."""
+        if self.X_mask is None or self.X_mask.shape[-2] != 1:
+            return None
+        c = self.__dict__.get("_vbmp_xmask_union")
+        if c is None or c[0] != px:
+            xm = self.X_mask[..., 0, :px].reshape(-1, px).bool()               # (batch elements, px)
+            free = (xm.unsqueeze(-1) & xm.unsqueeze(-2)).any(0).reshape(-1)    # union over the batch of xm (x) xm
+            keep = torch.nonzero(free).reshape(-1)
+            c = self._vbmp_xmask_union = (px, keep if 2 * keep.numel() <= px * px else None)
+        return c[1]
 
     def _residual_y(self, Y):
         """-1/2 y' E[R] y - n/2 log 2pi + 1/2 E log|R|  (one K3a launch)"""

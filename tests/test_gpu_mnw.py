@@ -455,3 +455,30 @@ def test_mnw_expectations_cache_follows_graph_replays():
         assert_close(seen[i], _composed_expectations(ref)[2], tol=1e-10)
     assert_close(m.EinvUX(), _composed_expectations(ref)[1], tol=1e-10)
     g.close()
+
+
+def test_trace_term_on_the_unmasked_entries_only(monkeypatch):
+    """Elog_like_given_pX_pY with an X_mask: the covariance trace runs over the entries that the mask leaves free in some batch
+    element (E[X' invU X] is exactly zero elsewhere) == the trace over all entries"""
+    from pyvbmp_amd.dists.MultivariateNormal_vector_format import MultivariateNormal_vector_format as MVN
+    from pyvbmp_amd.transforms.MatrixNormalWishart import MatrixNormalWishart
+    torch.manual_seed(11)
+    dt, K, n, px = torch.float64, 7, 3, 12
+    xm = torch.zeros(K, 1, px, dtype=torch.bool, device="cuda")
+    for k in range(K):
+        xm[k, 0, (k % 4) * 3:(k % 4) * 3 + 3] = True  # every expert reads three of the twelve inputs
+    m = MatrixNormalWishart((n, px), (K,), X_mask=xm, pad_X=False, device="cuda", dtype=dt)
+    X = torch.randn(300, 1, px, 1, device="cuda", dtype=dt)
+    Y = torch.randn(300, K, n, 1, device="cuda", dtype=dt)
+    m.raw_update(X, Y, lr=1.0)
+    A = torch.randn(40, 1, px, px, device="cuda", dtype=dt)
+    pX = MVN(mu=torch.randn(40, 1, px, 1, device="cuda", dtype=dt), Sigma=A @ A.mT + torch.eye(px, device="cuda", dtype=dt))
+    B = torch.randn(40, 1, n, n, device="cuda", dtype=dt)
+    pY = MVN(mu=torch.randn(40, 1, n, 1, device="cuda", dtype=dt), Sigma=B @ B.mT + torch.eye(n, device="cuda", dtype=dt))
+    keep = m._xmask_union(px)
+    assert keep is not None and keep.numel() == 4 * 9  # four distinct 3 x 3 blocks of the 144 entries
+    got = m.Elog_like_given_pX_pY(pX, pY)
+    monkeypatch.setattr(MatrixNormalWishart, "_xmask_union", lambda self, d: None)
+    want = m.Elog_like_given_pX_pY(pX, pY)
+    assert got.shape == want.shape == (40, K)
+    assert_close(got, want, tol=1e-12)
