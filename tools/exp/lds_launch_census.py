@@ -41,3 +41,6 @@ census("x0.EXTinvUX + ElogdetinvSigma + EinvSigma + EinvSigmamu", lambda: (x0.EX
 census("A.ElogdetinvSigma", lambda: A.ElogdetinvSigma())
 census("forward_backward_loop", lambda: m.forward_backward_loop(yy, uu, rr, sums_only=True))
 census("update_latents", lambda: m.update_latents(yy, uu, rr))
+if "--src" in sys.argv:
+    from tools.exp._census import by_source
+    by_source("update_latents", lambda: m.update_latents(yy, uu, rr))
