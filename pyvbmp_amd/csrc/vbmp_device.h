@@ -232,30 +232,28 @@ __device__ __forceinline__ void fmac_self8(float* acc, float f) {
                  [a5] "+v"(acc[5]), [a6] "+v"(acc[6]), [a7] "+v"(acc[7])
                : [f] "v"(f), [src] "n"(SRC));
 }
-template <int G, int SRC, int Dp, typename T>
+// (NC: the leading columns to update -- Dp, or the true size of an unpadded compile-time instance: the identity padding beyond it
+// never changes)
+template <int G, int SRC, int Dp, typename T, int NC = Dp>
 __device__ __forceinline__ void fmac_self_row(T (&acc)[Dp], T f) {
-  if constexpr (G == 16 && Dp % 8 == 0) {
+  constexpr int N8 = (G == 16) ? NC / 8 : 0;  // groups of eight, then of four, then single columns
+  constexpr int N4 = (NC - 8 * N8) / 4;
 #pragma unroll
-    for (int c = 0; c < Dp / 8; ++c) fmac_self8<G, SRC>(&acc[8 * c], f);
-  } else if constexpr (Dp % 4 == 0) {
+  for (int c = 0; c < N8; ++c) fmac_self8<G, SRC>(&acc[8 * c], f);
 #pragma unroll
-    for (int c = 0; c < Dp / 4; ++c) fmac_self4<G, SRC>(&acc[4 * c], f);
-  } else {
+  for (int c = 0; c < N4; ++c) fmac_self4<G, SRC>(&acc[8 * N8 + 4 * c], f);
 #pragma unroll
-    for (int j = 0; j < Dp; ++j) acc[j] = xfma(bcast<G, SRC>(acc[j]), f, acc[j]);
-  }
+  for (int j = 8 * N8 + 4 * N4; j < NC; ++j) acc[j] = xfma(bcast<G, SRC>(acc[j]), f, acc[j]);
 }
 
-// acc[0..Dp) += f * (piv[0..Dp) on lane SRC)
-template <int G, int SRC, int Dp, typename T>
+// acc[0..NC) += f * (piv[0..NC) on lane SRC)
+template <int G, int SRC, int Dp, typename T, int NC = Dp>
 __device__ __forceinline__ void fmac_bcast_row(T (&acc)[Dp], const T (&piv)[Dp], T f) {
-  if constexpr (Dp % 4 == 0) {
+  constexpr int N4 = NC / 4;
 #pragma unroll
-    for (int c = 0; c < Dp / 4; ++c) fmac_bcast4<G, SRC>(&acc[4 * c], &piv[4 * c], f);
-  } else {
+  for (int c = 0; c < N4; ++c) fmac_bcast4<G, SRC>(&acc[4 * c], &piv[4 * c], f);
 #pragma unroll
-    for (int j = 0; j < Dp; ++j) acc[j] = xfma(bcast<G, SRC>(piv[j]), f, acc[j]);
-  }
+  for (int j = 4 * N4; j < NC; ++j) acc[j] = xfma(bcast<G, SRC>(piv[j]), f, acc[j]);
 }
 
 // ---------------------------------------------------------------- scalar helpers
@@ -575,13 +573,17 @@ __device__ __forceinline__ void tile_rows2lds(T* __restrict__ lds, int mloc, int
 // in the row, so the scale is applied once at the end -- this removes Dp multiplies per step and
 // lets every other row consume the UNSCALED pivot row straight out of the owner's registers
 // through the DPP operand of the FMA.
-template <typename T, int Dp, int G, int R>
+// DX > 0: the matrix is DX x DX (compile-time) inside its identity-padded Dp x Dp image: only the DX pivots, the DX leading columns and
+// the row slots that hold a row < DX are worked on -- the padding stays the identity by itself (its multipliers are exact zeros), and
+// the DX x DX block comes out bit for bit as from the full elimination.  D = 20 in a 32-image: 800 instead of 2 048 FMAs per tile.
+template <typename T, int Dp, int G, int R, int DX = 0>
 __device__ __forceinline__ void gj_inverse(T (&a)[R][Dp], int lig, LogDet<T>& ld) {
   static_assert(R * G == Dp, "rows per lane x lanes per matrix must cover the padded dim");
+  constexpr int DN = DX > 0 ? DX : Dp;
   T sc[R];
 #pragma unroll
   for (int q = 0; q < R; ++q) sc[q] = T(1);
-  static_for<0, Dp>([&](auto K) {
+  static_for<0, DN>([&](auto K) {
     constexpr int k = decltype(K)::value;
     constexpr int src = k % G;   // lane (in group) that owns the pivot row
     constexpr int slot = k / G;  // ... and the slot it sits in
@@ -593,19 +595,23 @@ __device__ __forceinline__ void gj_inverse(T (&a)[R][Dp], int lig, LogDet<T>& ld
     // rows in the pivot slot go last: their destination registers are this step's DPP sources
     static_for<0, R>([&](auto Q) {
       constexpr int q = (decltype(Q)::value + slot + 1) % R;
-      const bool is_piv = owner && (q == slot);
-      const T nf = is_piv ? T(0) : -(a[q][k] * p);
-      if constexpr (q == slot)
-        fmac_self_row<G, src, Dp, T>(a[q], nf);
-      else
-        fmac_bcast_row<G, src, Dp, T>(a[q], a[slot], nf);
-      a[q][k] = is_piv ? T(1) : nf;
+      if constexpr (q * G < DN) {  // (a slot of padding rows only: nothing to do)
+        const bool is_piv = owner && (q == slot);
+        const T nf = is_piv ? T(0) : -(a[q][k] * p);
+        if constexpr (q == slot)
+          fmac_self_row<G, src, Dp, T, DN>(a[q], nf);
+        else
+          fmac_bcast_row<G, src, Dp, T, DN>(a[q], a[slot], nf);
+        a[q][k] = is_piv ? T(1) : nf;
+      }
     });
   });
 #pragma unroll
   for (int q = 0; q < R; ++q)
+    if (q * G < DN) {
 #pragma unroll
-    for (int j = 0; j < Dp; ++j) a[q][j] *= sc[q];
+      for (int j = 0; j < DN; ++j) a[q][j] *= sc[q];
+    }
 }
 
 // ---------------------------------------------------------------- quadratic form + logdet only
