@@ -4,7 +4,8 @@
 #define VBMP_DBG_NT_LOAD        0x1        /* K1/K2: non-temporal tile loads */
 #define VBMP_DBG_NT_STORE       0x2        /* K1/K2: non-temporal tile stores */
 #define VBMP_DBG_PLAIN_ORDER    0x4        /* K1/K2: tiles in plain blockIdx order (round 2) instead of XCD-contiguous */
-#define VBMP_DBG_BLK_INV_WAVES  0x8        /* K9 block form, -DVBMP_BLK_INV_MFMA builds: inverses by one wave per matrix instead of the matrix-core block Gauss-Jordan */
+#define VBMP_DBG_BLK_INV_WAVES  0x40000000 /* K9 block form, -DVBMP_BLK_INV_MFMA builds only: inverses by one wave per matrix instead of the matrix-core block Gauss-Jordan */
+#define VBMP_DBG_ROWS_DIRECT     0x8        /* K12 + quad: a row per thread straight from global memory (round 2) instead of rows staged through LDS */
 #define VBMP_DBG_LDS_LANES      0x10       /* K9: lane-per-series form */
 #define VBMP_DBG_LDS_ROWS       0x20       /* K9: row-per-lane form */
 #define VBMP_DBG_K1_WAVE        0x40       /* K1: one wave per matrix */

@@ -1,6 +1,6 @@
 """K9 block form, library built with -DVBMP_BLK_INV_MFMA (tools/exp/build_variant.sh NAME "k_lds_f64 k_lds_f32" -DVBMP_BLK_INV_MFMA
 -mllvm -amdgpu-mfma-vgpr-form; pass its path as argv[2]): inverses as block Gauss-Jordan on the matrix cores against one wave per matrix
-(VBMP_DBG_BLK_INV_WAVES = 0x8): smoother time per call and the difference of the outputs."""
+(VBMP_DBG_BLK_INV_WAVES = 0x40000000): smoother time per call and the difference of the outputs."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -22,7 +22,7 @@ for dt in (torch.float64, torch.float32):
         yy, uu, rr = m.reshape_inputs(y)
         m.update_latents(yy, uu, rr)
         res = {}
-        for name, flag in (("mfma", 0), ("waves", 0x8)):
+        for name, flag in (("mfma", 0), ("waves", 0x40000000)):
             lib.vbmp_debug_set_flags(flag)
             outs = m.forward_backward_loop(yy, uu, rr)
             ev = []
