@@ -576,8 +576,10 @@ __device__ __forceinline__ void tile_rows2lds(T* __restrict__ lds, int mloc, int
 // DX > 0: the matrix is DX x DX (compile-time) inside its identity-padded Dp x Dp image: only the DX pivots, the DX leading columns and
 // the row slots that hold a row < DX are worked on -- the padding stays the identity by itself (its multipliers are exact zeros), and
 // the DX x DX block comes out bit for bit as from the full elimination.  D = 20 in a 32-image: 800 instead of 2 048 FMAs per tile.
+// Drt >= 0 (run-time size of an unpadded matrix, wave-uniform; the run-time-D instances): the pivots k >= Drt are skipped -- each is a
+// pivot of 1 on a unit row, a step that changes nothing -- at the price of one scalar branch per pivot.
 template <typename T, int Dp, int G, int R, int DX = 0>
-__device__ __forceinline__ void gj_inverse(T (&a)[R][Dp], int lig, LogDet<T>& ld) {
+__device__ __forceinline__ void gj_inverse(T (&a)[R][Dp], int lig, LogDet<T>& ld, int Drt = -1) {
   static_assert(R * G == Dp, "rows per lane x lanes per matrix must cover the padded dim");
   constexpr int DN = DX > 0 ? DX : Dp;
   T sc[R];
@@ -585,6 +587,7 @@ __device__ __forceinline__ void gj_inverse(T (&a)[R][Dp], int lig, LogDet<T>& ld
   for (int q = 0; q < R; ++q) sc[q] = T(1);
   static_for<0, DN>([&](auto K) {
     constexpr int k = decltype(K)::value;
+    if (Drt >= 0 && k >= Drt) return;  // (folds away where Drt is the literal -1)
     constexpr int src = k % G;   // lane (in group) that owns the pivot row
     constexpr int slot = k / G;  // ... and the slot it sits in
     const bool owner = (G == 1) || (lig == src);
