@@ -537,8 +537,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
         try:
+            if args.backend == "nccl" and world > torch.cuda.device_count():
+                # several ranks on one card: RCCL refuses a duplicate device -- on most boxes at once, on some only after hanging
+                # in its bootstrap past any timeout (seen once: 7 silent minutes).  Known before trying, so not tried.
+                raise RuntimeError(f"{world} ranks share {torch.cuda.device_count()} device(s): backend nccl cannot start "
+                                   "(duplicate device), not attempted")
             dist.init_process_group(args.backend, device_id=device if args.backend == "nccl" else None,
-                                    timeout=datetime.timedelta(seconds=300))
+                                    timeout=datetime.timedelta(seconds=120))
             probe = torch.ones(1, device=device)
             dist.all_reduce(probe)  # the first collective: surface a transport that cannot run HERE, before any timing
             torch.cuda.synchronize()
